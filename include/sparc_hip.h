@@ -1,0 +1,163 @@
+/*
+ * sparc_hip.h -- C ABI of libsparc_hip.so: the MI355X (gfx950) kernels behind the
+ * SpectralNet training step of SPARC.
+ *
+ * The reference implements this path in Python on dense torch tensors and has no
+ * foreign-function interface of its own; each entry point below names the lines
+ * of the reference (relative to its checkout) whose work it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its comment says "host";
+ *   - every function enqueues work on `stream` and returns at once: 0 on success,
+ *     a negative SPARC_ERR_* code otherwise; nothing throws, nothing synchronises
+ *     except where stated, nothing allocates: scratch memory is passed in through
+ *     `ws` (size from the matching *_workspace_bytes query, 256-byte aligned);
+ *   - matrices are row-major float unless stated; k is the spectral dimension
+ *     (<= 64); m is the number of nodes of one cluster batch;
+ *   - calls on distinct streams with distinct workspaces may run concurrently.
+ *
+ * Sparse format ("dual-value CSR").  A batch's support matrix A is stored once:
+ *     rowptr  int64[m+1], colidx int32[nnz] (sorted inside a row),
+ *     val     float[nnz]  = A[i, j]      for the entry (i, j = colidx[p]),
+ *     valT    float[nnz]  = A[j, i]      (the mirrored entry; 0 if absent).
+ * The sparsity pattern is symmetrised at build time, so A^T x is evaluated with the
+ * same row gather as A x, using valT instead of val: no transposed copy exists.
+ * valT may be NULL when the matrix is numerically symmetric.
+ */
+#ifndef SPARC_HIP_H
+#define SPARC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* sparc_stream_t; /* == hipStream_t */
+
+#define SPARC_OK 0
+#define SPARC_ERR_ARG (-1)     /* bad argument (NULL pointer, k out of range, ...) */
+#define SPARC_ERR_WS (-2)      /* workspace too small or misaligned */
+#define SPARC_ERR_LAUNCH (-3)  /* the HIP runtime refused a launch */
+
+#define SPARC_MAX_K 64
+/* per-row constants used by the per-step kernels, float[m][8] */
+#define SPARC_ROWC 8 /* {1/rho, g, d + cw, 1/sqrt(d), r, r2, c, c2} */
+
+int sparc_abi_version(void);
+
+/* ---- support matrix: COO tuple -> dual-value CSR -----------------------------------
+ * Replaces SpectralTrainer._get_support_matrix (src/SpectralTrainer.py:275-281): the
+ * reference casts the float64 values to float32 and densifies the COO (repeated
+ * coordinates add up) on every step; here the tuple is sorted and merged once.
+ * coords is int32[nnz_in][2] = (row, col) as written by to_tuple (src/utils.py:41-47).
+ * Outputs must have room for 2*nnz_in entries (the symmetrised pattern); the number
+ * actually used is written to *nnz_out, and *is_symmetric is 1 iff val == valT
+ * everywhere.  Both are device words; read them back after synchronising. */
+size_t sparc_csr_build_workspace_bytes(int64_t m, int64_t nnz_in);
+int sparc_csr_build(int64_t m, int64_t nnz_in, const int32_t* coords, const double* values,
+                    int64_t* rowptr, int32_t* colidx, float* val, float* valT,
+                    int64_t* nnz_out, int32_t* is_symmetric,
+                    void* ws, size_t ws_bytes, sparc_stream_t stream);
+
+/* ---- affinity: the per-batch vectors of W ---------------------------------------------
+ * Replaces SpectralTrainer._get_valid_affinity_matrix (src/SpectralTrainer.py:284-293)
+ * and the row sums of SpectralNetLoss (src/SpectralTrainer.py:133).  With eps = 1e-6,
+ * S = A + A^2 + A^3, U = [1 r r2], V = [1 c c2] (r = A1, c = A^T 1, r2 = A r,
+ * c2 = A^T c) the reference's dense matrix is
+ *     W = diag(1/rho) (S + U C V^T - diag(g)),
+ * g the removed diagonal and rho the row 2-norms.  Run once per batch (W depends on the
+ * support only).  Outputs: rowc float[m][SPARC_ROWC] as defined above; vec float[3][m] =
+ * {d = W 1, cw = W^T 1, rho}; coupling double[16] = {C row-major (9), m, s = 1^T A 1, ...}. */
+size_t sparc_affinity_prep_workspace_bytes(int64_t m, int64_t nnz);
+int sparc_affinity_prep(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* colidx,
+                        const float* val, const float* valT, float eps,
+                        float* rowc, float* vec, double* coupling,
+                        void* ws, size_t ws_bytes, sparc_stream_t stream);
+
+/* ---- Laplacian product + spectral loss (+ gradient) ---------------------------------------
+ * Replaces SpectralNetLoss.forward with is_normalized=True (src/SpectralTrainer.py:130-137)
+ * and its autograd backward (:237).  Computes, with Yn = Y / sqrt(d),
+ *     loss  = tr(Yn^T (1/2 (D_r + D_c) - W) Yn) / m          (== sum(W * cdist(Yn)^2) / 2m)
+ *     gradY = [(d + cw) * Yn - W Yn - W^T Yn] / (m sqrt(d))   (only if gradY != NULL)
+ * by three chained CSR products (Horner form of A + A^2 + A^3) whose last pass carries the
+ * rank-3 correction, the diagonal removal, the row scaling, the per-row dot products of the
+ * loss and the gradient in its epilogue.  Y is [m][ldy] with k <= ldy; gradY is [m][ldy].
+ * loss is one device double. */
+size_t sparc_lap_workspace_bytes(int64_t m, int k);
+int sparc_lap_fwd(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* colidx,
+                  const float* val, const float* valT, const float* rowc, const double* coupling,
+                  int k, int64_t ldy, const float* Y, double* loss, float* gradY,
+                  void* ws, size_t ws_bytes, sparc_stream_t stream);
+
+/* Plain product Z = A X (+ X0 if X0 != NULL) on the same kernel, X, X0, Z [m][width] with
+ * width in {16, 32, 64, 128}.  Exposed for roofline measurements on whole graphs. */
+int sparc_spmm(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* colidx,
+               const float* val, int width, const float* X, const float* X0, float* Z,
+               sparc_stream_t stream);
+
+/* ---- orthonormalisation layer ------------------------------------------------------------------
+ * Replaces SpectralNetModel._make_orthonorm_weights (src/SpectralTrainer.py:42-70): the
+ * reference takes R from a Householder QR of Yt [m][k], multiplies its columns by
+ * sign(diag R) and returns sqrt(m) inverse(R).  That equals sqrt(m) S Rc^-1 S with Rc the
+ * Cholesky factor (upper, positive diagonal) of the Gram matrix Yt^T Yt and S the signs of
+ * the Householder diagonal; S is reproduced from the k rows `top_idx` (the first k rows of
+ * the reference's permuted batch; NULL = rows 0..k-1).
+ *
+ * sparc_gram:         G = A^T B, double [k][k], A and B float [m][ld*]; MFMA f64, fixed
+ *                     summation order (bitwise reproducible).
+ * sparc_orth_weights: mode 0 = reference (with S), 1 = S = I.  Wo float[k][k]; saved for the
+ *                     backward: Rc, Rinv double[k][k], signs double[k]; *info (device int) is
+ *                     set to j+1 if the Gram matrix is not positive definite at pivot j.
+ * sparc_orth_apply:   Z = Yt Wo (transpose_w = 0) or Yt Wo^T (1): SpectralNetModel.forward's
+ *                     last line (src/SpectralTrainer.py:103) and its backward wrt Yt.
+ * sparc_orth_weights_bwd: given gWo = d loss / d Wo (double [k][k]) returns H = Gbar + Gbar^T
+ *                     (float [k][k]) such that d loss / d Yt = Yt H: the backward of the
+ *                     reference's qr -> R@D -> inverse chain (autograd, :237). */
+size_t sparc_gram_workspace_bytes(int64_t m, int k);
+int sparc_gram(int64_t m, int k, const float* A, int64_t lda, const float* B, int64_t ldb,
+               double* G, void* ws, size_t ws_bytes, sparc_stream_t stream);
+int sparc_orth_weights(int64_t m, int k, const double* G, const float* Yt, int64_t ld,
+                       const int32_t* top_idx, int mode, float* Wo,
+                       double* Rc, double* Rinv, double* signs, int32_t* info,
+                       sparc_stream_t stream);
+int sparc_orth_apply(int64_t m, int k, const float* Yt, int64_t ld, const float* Wo,
+                     int transpose_w, float* Z, int64_t ldz, sparc_stream_t stream);
+int sparc_orth_weights_bwd(int64_t m, int k, const double* gWo, const double* Rc,
+                           const double* Rinv, const double* signs, int mode, float* H,
+                           sparc_stream_t stream);
+
+/* ---- support / degree construction -----------------------------------------------------------
+ * Replaces the sparse algebra of preprocess_multicluster / preprocess (src/utils.py:60-137):
+ * the induced sub-block adj[pt,:][:,pt] (:83, :126), normalize_adj (:22-27),
+ * normalize_adj_diag_enhance (:30-38) and to_tuple (:41-47), all in float64 with one
+ * rounding per reference operation so that values, indices and degree arrays are
+ * bit-identical to SciPy's (after sorting a tuple by (row, col)).
+ *
+ * Graph CSR: indptr int64[n+1], indices int32, data double (sorted inside a row).
+ * pt int32[m] lists the batch's nodes (no repeats); local index = position in pt.
+ * flavour = mode | (binarize << 4).  mode 0: the raw sub-block; mode 1: rows scaled by
+ * 1/max(1, rowsum) (normalize_adj); mode 2: (D+I)^-1 (A+I) then diagonal += diag_lambda *
+ * diagonal (normalize_adj_diag_enhance).  binarize replaces every stored value by 1 first:
+ * that is partition_graph's intra-part adjacency (src/partition_utils.py:69-74), whose rows,
+ * for pt = one part, equal the sub-block's rows, so the validation path (:113-116, :126)
+ * is mode 1 or 2 with binarize set, and the training path (:83-89) is mode 0 or 2 without.
+ * Pass 1 (count) writes row_nnz int64[m+1] (exclusive prefix, total in [m]) and the float64
+ * degree array rowsum[m] (the rowsum of the matrix the flavour normalises by);
+ * pass 2 (fill) writes coords int32[total][2] sorted by (row, col) and values double[total]. */
+size_t sparc_subblock_workspace_bytes(int64_t n, int64_t m);
+int sparc_subblock_count(int64_t n, const int64_t* indptr, const int32_t* indices, const double* data,
+                         int64_t m, const int32_t* pt, int flavour,
+                         int64_t* row_nnz, double* rowsum,
+                         void* ws, size_t ws_bytes, sparc_stream_t stream);
+int sparc_subblock_fill(int64_t n, const int64_t* indptr, const int32_t* indices, const double* data,
+                        int64_t m, const int32_t* pt, int flavour, double diag_lambda,
+                        const int64_t* row_nnz, const double* rowsum,
+                        int32_t* coords, double* values,
+                        void* ws, size_t ws_bytes, sparc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPARC_HIP_H */

@@ -1,0 +1,60 @@
+"""ctypes binding of libsparc_hip.so (the C ABI declared in include/sparc_hip.h).
+
+The library is mandatory: there is no CPU or eager fallback.  If it has not been
+built (python -m sparc_amd.build) importing this module raises.
+"""
+import ctypes
+import os
+from ctypes import c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsparc_hip.so")
+
+ERRORS = {-1: "SPARC_ERR_ARG (bad argument)", -2: "SPARC_ERR_WS (workspace too small or misaligned)",
+          -3: "SPARC_ERR_LAUNCH (HIP launch failed)"}
+
+
+class SparcHipError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise SparcHipError(
+            f"{LIB_PATH} is missing: build the HIP extension first (python -m sparc_amd.build); "
+            "sparc_amd has no fallback path")
+    return ctypes.CDLL(LIB_PATH)
+
+
+lib = _load()
+
+P = c_void_p
+_SIGS = {
+    "sparc_abi_version": (c_int, []),
+    "sparc_csr_build_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "sparc_csr_build": (c_int, [c_int64, c_int64, P, P, P, P, P, P, P, P, P, c_size_t, P]),
+    "sparc_affinity_prep_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "sparc_affinity_prep": (c_int, [c_int64, c_int64, P, P, P, P, c_float, P, P, P, P, c_size_t, P]),
+    "sparc_lap_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "sparc_lap_fwd": (c_int, [c_int64, c_int64, P, P, P, P, P, P, c_int, c_int64, P, P, P, P, c_size_t, P]),
+    "sparc_spmm": (c_int, [c_int64, c_int64, P, P, P, c_int, P, P, P, P]),
+    "sparc_gram_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "sparc_gram": (c_int, [c_int64, c_int, P, c_int64, P, c_int64, P, P, c_size_t, P]),
+    "sparc_orth_weights": (c_int, [c_int64, c_int, P, P, c_int64, P, c_int, P, P, P, P, P, P]),
+    "sparc_orth_apply": (c_int, [c_int64, c_int, P, c_int64, P, c_int, P, c_int64, P]),
+    "sparc_orth_weights_bwd": (c_int, [c_int64, c_int, P, P, P, P, c_int, P, P]),
+    "sparc_subblock_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "sparc_subblock_count": (c_int, [c_int64, P, P, P, c_int64, P, c_int, P, P, P, c_size_t, P]),
+    "sparc_subblock_fill": (c_int, [c_int64, P, P, P, c_int64, P, c_int, c_double, P, P, P, P, P, c_size_t, P]),
+}
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(lib, _name)
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+EXPORTS = tuple(_SIGS)
+
+
+def check(rc, what):
+    if rc != 0:
+        raise SparcHipError(f"{what} failed: {ERRORS.get(rc, rc)}")

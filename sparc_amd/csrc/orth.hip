@@ -1,0 +1,337 @@
+// Orthonormalisation layer: Gram matrix on the f64 matrix cores, k x k Cholesky,
+// triangular inverse and Householder sign recovery in LDS, the product with the
+// orthonormalisation weights, and the backward of the whole chain.
+#include "common.h"
+
+namespace {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+constexpr int GRAM_MAX_BLOCKS = 256;
+
+// G_b = P[rows of block b]^T Q[rows of block b], accumulated in float64 by
+// v_mfma_f64_16x16x4_f64.  Lane l feeds A[i = l&15][kk = l>>4] = P[r0+kk][16 ti + i] and
+// B[kk][j = l&15] = Q[r0+kk][16 tj + j]; result register q of lane l is
+// G[16 ti + (l>>4) + 4 q][16 tj + (l&15)].
+template <int NT>
+__global__ __launch_bounds__(256) void gram_partial(int64_t m, int k, const float* __restrict__ P, int64_t ldp,
+                                                    const float* __restrict__ Q, int64_t ldq,
+                                                    int64_t rows_per_block, double* __restrict__ slab) {
+    constexpr int KP = NT * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int64_t base = blockIdx.x * rows_per_block;
+    const int64_t end = min(m, base + rows_per_block);
+    double4_t acc[NT][NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
+
+    for (int64_t r0 = base + wave * 4; r0 < end; r0 += 16) {
+        const int64_t r = r0 + lk;
+        const bool live = r < end;
+        double pa[NT], qb[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int cidx = t * 16 + li;
+            const bool ok = live && cidx < k;
+            pa[t] = ok ? static_cast<double>(P[r * ldp + cidx]) : 0.0;
+            qb[t] = ok ? static_cast<double>(Q[r * ldq + cidx]) : 0.0;
+        }
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[a], qb[b], acc[a][b], 0, 0, 0);
+    }
+
+    // waves add into one LDS image in wave order (fixed summation order)
+    __shared__ double sm[KP * KP];
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int gi = a * 16 + lk + 4 * q, gj = b * 16 + li;
+                        const double v = acc[a][b][q];
+                        if (w == 0) sm[gi * KP + gj] = v; else sm[gi * KP + gj] += v;
+                    }
+        }
+        __syncthreads();
+    }
+    double* out = slab + static_cast<int64_t>(blockIdx.x) * k * k;
+    for (int e = threadIdx.x; e < k * k; e += 256) out[e] = sm[(e / k) * KP + (e % k)];
+}
+
+__global__ void gram_reduce(int kk, int nparts, const double* __restrict__ slab, double* __restrict__ G) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= kk) return;
+    double t = 0.0;
+    for (int b = 0; b < nparts; ++b) t += slab[static_cast<int64_t>(b) * kk + e];
+    G[e] = t;
+}
+
+// Single workgroup.  LDS images: R (Gram, then its Cholesky factor, upper), X = R^-1, Q.
+__global__ __launch_bounds__(256) void orth_weights_kernel(int64_t m, int k, const double* __restrict__ G,
+                                                           const float* __restrict__ Yt, int64_t ld,
+                                                           const int32_t* __restrict__ top_idx, int mode,
+                                                           float* __restrict__ Wo, double* __restrict__ Rc_out,
+                                                           double* __restrict__ Rinv_out, double* __restrict__ signs_out,
+                                                           int32_t* __restrict__ info) {
+    __shared__ double R[SPARC_MAX_K * SPARC_MAX_K];
+    __shared__ double X[SPARC_MAX_K * SPARC_MAX_K];
+    __shared__ double Q[SPARC_MAX_K * SPARC_MAX_K];
+    __shared__ double sg[SPARC_MAX_K];
+    __shared__ int bad;
+    const int tid = threadIdx.x;
+    if (tid == 0) bad = 0;
+    for (int e = tid; e < k * k; e += 256) { R[e] = G[e]; X[e] = 0.0; }
+    __syncthreads();
+
+    // Cholesky, upper: G = R^T R
+    for (int j = 0; j < k; ++j) {
+        if (tid == 0) {
+            double piv = R[j * k + j];
+            if (!(piv > 0.0)) { if (!bad) bad = j + 1; piv = 1e-300; }
+            R[j * k + j] = sqrt(piv);
+        }
+        __syncthreads();
+        const double dj = R[j * k + j];
+        for (int c = j + 1 + tid; c < k; c += 256) R[j * k + c] /= dj;
+        __syncthreads();
+        const int n = k - j - 1;
+        for (int e = tid; e < n * n; e += 256) {
+            const int a = j + 1 + e / n, b = j + 1 + e % n;
+            if (a <= b) R[a * k + b] -= R[j * k + a] * R[j * k + b];
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < k * k; e += 256)
+        if (e / k > e % k) R[e] = 0.0;
+    __syncthreads();
+
+    // X = R^-1 (upper), one column per thread
+    if (tid < k) {
+        const int c = tid;
+        X[c * k + c] = 1.0 / R[c * k + c];
+        for (int i = c - 1; i >= 0; --i) {
+            double t = 0.0;
+            for (int l = i + 1; l <= c; ++l) t += R[i * k + l] * X[l * k + c];
+            X[i * k + c] = -t / R[i * k + i];
+        }
+    }
+    __syncthreads();
+
+    // Householder signs from the modified LU of Q = Yt[top] X
+    if (mode == 0) {
+        for (int e = tid; e < k * k; e += 256) {
+            const int a = e / k, b = e % k;
+            const int64_t row = top_idx ? top_idx[a] : a;
+            double t = 0.0;
+            if (row < m)
+                for (int l = 0; l <= b; ++l) t += static_cast<double>(Yt[row * ld + l]) * X[l * k + b];
+            Q[e] = t;
+        }
+        __syncthreads();
+        for (int i = 0; i < k; ++i) {
+            if (tid == 0) {
+                const double s = Q[i * k + i] > 0.0 ? -1.0 : 1.0;
+                sg[i] = s;
+                Q[i * k + i] -= s;
+            }
+            __syncthreads();
+            const double piv = Q[i * k + i];
+            for (int a = i + 1 + tid; a < k; a += 256) Q[a * k + i] /= piv;
+            __syncthreads();
+            const int n = k - i - 1;
+            for (int e = tid; e < n * n; e += 256) {
+                const int a = i + 1 + e / n, b = i + 1 + e % n;
+                Q[a * k + b] -= Q[a * k + i] * Q[i * k + b];
+            }
+            __syncthreads();
+        }
+    } else {
+        if (tid < k) sg[tid] = 1.0;
+        __syncthreads();
+    }
+
+    const double sq = sqrt(static_cast<double>(m));
+    for (int e = tid; e < k * k; e += 256) {
+        const int i = e / k, j = e % k;
+        Wo[e] = static_cast<float>(sq * sg[i] * X[e] * sg[j]);
+        Rc_out[e] = R[e];
+        Rinv_out[e] = X[e];
+    }
+    if (tid < k) signs_out[tid] = sg[tid];
+    if (tid == 0) *info = bad;
+}
+
+// C = op(A) op(B) for k x k matrices in LDS (row-major, stride k); out may not alias.
+__device__ void mm_kk(int k, const double* A, bool ta, const double* B, bool tb, double* C, double scale) {
+    for (int e = threadIdx.x; e < k * k; e += 256) {
+        const int i = e / k, j = e % k;
+        double t = 0.0;
+        for (int l = 0; l < k; ++l) {
+            const double a = ta ? A[l * k + i] : A[i * k + l];
+            const double b = tb ? B[j * k + l] : B[l * k + j];
+            t += a * b;
+        }
+        C[e] = scale * t;
+    }
+    __syncthreads();
+}
+
+// Backward of Wo = sqrt(m) S Rc^-1 S through Rc = chol(G)^T:  H = Gbar + Gbar^T, so that
+// d loss / d Yt = Yt H for G = Yt^T Yt.
+__global__ __launch_bounds__(256) void orth_weights_bwd_kernel(int64_t m, int k, const double* __restrict__ gWo,
+                                                               const double* __restrict__ Rc, const double* __restrict__ Rinv,
+                                                               const double* __restrict__ signs, int mode,
+                                                               float* __restrict__ H) {
+    __shared__ double M[SPARC_MAX_K * SPARC_MAX_K];   // Rc^-1
+    __shared__ double A[SPARC_MAX_K * SPARC_MAX_K];
+    __shared__ double B[SPARC_MAX_K * SPARC_MAX_K];
+    __shared__ double L[SPARC_MAX_K * SPARC_MAX_K];   // Rc (upper); L = Rc^T
+    const int tid = threadIdx.x;
+    const double sq = sqrt(static_cast<double>(m));
+    for (int e = tid; e < k * k; e += 256) {
+        const int i = e / k, j = e % k;
+        M[e] = Rinv[e];
+        L[e] = Rc[e];
+        const double s = (mode == 0) ? signs[i] * signs[j] : 1.0;
+        A[e] = (i <= j) ? sq * s * gWo[e] : 0.0;  // Mbar (upper part only: M is upper triangular)
+    }
+    __syncthreads();
+    mm_kk(k, A, false, M, true, B, 1.0);    // B = Mbar M^T
+    mm_kk(k, M, true, B, false, A, -1.0);   // A = Rbar = -M^T Mbar M^T
+    // Lbar = tril(Rbar^T): B[i][j] = Rbar[j][i] for i >= j
+    for (int e = tid; e < k * k; e += 256) {
+        const int i = e / k, j = e % k;
+        B[e] = (i >= j) ? A[j * k + i] : 0.0;
+    }
+    __syncthreads();
+    mm_kk(k, L, false, B, false, A, 1.0);   // A = L^T Lbar = Rc Lbar
+    for (int e = tid; e < k * k; e += 256) {
+        const int i = e / k, j = e % k;
+        A[e] = (i > j) ? A[e] : (i == j ? 0.5 * A[e] : 0.0);  // Phi
+    }
+    __syncthreads();
+    mm_kk(k, M, false, A, false, B, 1.0);   // B = M Phi
+    mm_kk(k, B, false, M, true, A, 1.0);    // A = Gbar = M Phi M^T
+    for (int e = tid; e < k * k; e += 256) {
+        const int i = e / k, j = e % k;
+        H[e] = static_cast<float>(A[e] + A[j * k + i]);
+    }
+}
+
+// Z[rows] = Yt[rows] Wo  (or Wo^T).  64 rows per block; thread (r, cg) owns KP/4 columns.
+template <int KP>
+__global__ __launch_bounds__(256) void orth_apply_kernel(int64_t m, int k, const float* __restrict__ Yt, int64_t ld,
+                                                         const float* __restrict__ Wo, int transpose_w,
+                                                         float* __restrict__ Z, int64_t ldz) {
+    constexpr int CT = KP / 4;  // columns per thread
+    __shared__ float Ws[KP][KP];
+    __shared__ float Ys[64][KP + 1];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < KP * KP; e += 256) {
+        const int i = e / KP, j = e % KP;
+        float w = 0.f;
+        if (i < k && j < k) w = transpose_w ? Wo[j * k + i] : Wo[i * k + j];
+        Ws[i][j] = w;
+    }
+    const int64_t r0 = static_cast<int64_t>(blockIdx.x) * 64;
+    for (int e = tid; e < 64 * KP; e += 256) {
+        const int r = e / KP, c = e % KP;
+        const int64_t row = r0 + r;
+        Ys[r][c] = (row < m && c < k) ? Yt[row * ld + c] : 0.f;
+    }
+    __syncthreads();
+    const int r = tid >> 2, cg = tid & 3;
+    float acc[CT];
+#pragma unroll
+    for (int q = 0; q < CT; ++q) acc[q] = 0.f;
+    for (int l = 0; l < KP; ++l) {
+        const float y = Ys[r][l];
+#pragma unroll
+        for (int q = 0; q < CT; ++q) acc[q] = fmaf(y, Ws[l][cg * CT + q], acc[q]);
+    }
+    const int64_t row = r0 + r;
+    if (row < m) {
+#pragma unroll
+        for (int q = 0; q < CT; ++q) {
+            const int c = cg * CT + q;
+            if (c < k) Z[row * ldz + c] = acc[q];
+        }
+    }
+}
+
+int gram_blocks(int64_t m) {
+    int64_t nb = (m + 63) / 64;
+    if (nb > GRAM_MAX_BLOCKS) nb = GRAM_MAX_BLOCKS;
+    if (nb < 1) nb = 1;
+    return static_cast<int>(nb);
+}
+
+}  // namespace
+
+extern "C" size_t sparc_gram_workspace_bytes(int64_t m, int k) {
+    if (m < 0 || k < 1 || k > SPARC_MAX_K) return 0;
+    return sparc_align_up(static_cast<size_t>(gram_blocks(m)) * k * k * sizeof(double));
+}
+
+extern "C" int sparc_gram(int64_t m, int k, const float* A, int64_t lda, const float* B, int64_t ldb, double* G,
+                          void* ws, size_t ws_bytes, sparc_stream_t stream) {
+    if (m <= 0 || k < 1 || k > SPARC_MAX_K || !A || !B || !G || lda < k || ldb < k) return SPARC_ERR_ARG;
+    if (!ws || ws_bytes < sparc_gram_workspace_bytes(m, k) || (reinterpret_cast<uintptr_t>(ws) & 255)) return SPARC_ERR_WS;
+    const int nb = gram_blocks(m);
+    int64_t rpb = (m + nb - 1) / nb;
+    rpb = (rpb + 15) / 16 * 16;
+    const int nparts = static_cast<int>((m + rpb - 1) / rpb);
+    double* slab = static_cast<double*>(ws);
+    const int nt = (k + 15) / 16;
+    const dim3 g(static_cast<unsigned>(nparts)), b(256);
+    switch (nt) {
+        case 1: hipLaunchKernelGGL((gram_partial<1>), g, b, 0, stream, m, k, A, lda, B, ldb, rpb, slab); break;
+        case 2: hipLaunchKernelGGL((gram_partial<2>), g, b, 0, stream, m, k, A, lda, B, ldb, rpb, slab); break;
+        case 3: hipLaunchKernelGGL((gram_partial<3>), g, b, 0, stream, m, k, A, lda, B, ldb, rpb, slab); break;
+        default: hipLaunchKernelGGL((gram_partial<4>), g, b, 0, stream, m, k, A, lda, B, ldb, rpb, slab); break;
+    }
+    SPARC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gram_reduce, dim3((k * k + 255) / 256), b, 0, stream, k * k, nparts, slab, G);
+    SPARC_CHECK_LAUNCH();
+    return SPARC_OK;
+}
+
+extern "C" int sparc_orth_weights(int64_t m, int k, const double* G, const float* Yt, int64_t ld,
+                                  const int32_t* top_idx, int mode, float* Wo, double* Rc, double* Rinv,
+                                  double* signs, int32_t* info, sparc_stream_t stream) {
+    if (m <= 0 || k < 1 || k > SPARC_MAX_K || !G || !Yt || ld < k || !Wo || !Rc || !Rinv || !signs || !info ||
+        (mode != 0 && mode != 1))
+        return SPARC_ERR_ARG;
+    hipLaunchKernelGGL(orth_weights_kernel, dim3(1), dim3(256), 0, stream, m, k, G, Yt, ld, top_idx, mode, Wo, Rc, Rinv,
+                       signs, info);
+    SPARC_CHECK_LAUNCH();
+    return SPARC_OK;
+}
+
+extern "C" int sparc_orth_weights_bwd(int64_t m, int k, const double* gWo, const double* Rc, const double* Rinv,
+                                      const double* signs, int mode, float* H, sparc_stream_t stream) {
+    if (m <= 0 || k < 1 || k > SPARC_MAX_K || !gWo || !Rc || !Rinv || !signs || !H) return SPARC_ERR_ARG;
+    hipLaunchKernelGGL(orth_weights_bwd_kernel, dim3(1), dim3(256), 0, stream, m, k, gWo, Rc, Rinv, signs, mode, H);
+    SPARC_CHECK_LAUNCH();
+    return SPARC_OK;
+}
+
+extern "C" int sparc_orth_apply(int64_t m, int k, const float* Yt, int64_t ld, const float* Wo, int transpose_w,
+                                float* Z, int64_t ldz, sparc_stream_t stream) {
+    if (m <= 0 || k < 1 || k > SPARC_MAX_K || !Yt || !Wo || !Z || ld < k || ldz < k) return SPARC_ERR_ARG;
+    const dim3 g(static_cast<unsigned>((m + 63) / 64)), b(256);
+    if (k <= 16) hipLaunchKernelGGL((orth_apply_kernel<16>), g, b, 0, stream, m, k, Yt, ld, Wo, transpose_w, Z, ldz);
+    else if (k <= 32) hipLaunchKernelGGL((orth_apply_kernel<32>), g, b, 0, stream, m, k, Yt, ld, Wo, transpose_w, Z, ldz);
+    else if (k <= 48) hipLaunchKernelGGL((orth_apply_kernel<48>), g, b, 0, stream, m, k, Yt, ld, Wo, transpose_w, Z, ldz);
+    else hipLaunchKernelGGL((orth_apply_kernel<64>), g, b, 0, stream, m, k, Yt, ld, Wo, transpose_w, Z, ldz);
+    SPARC_CHECK_LAUNCH();
+    return SPARC_OK;
+}
