@@ -43,7 +43,7 @@ typedef struct ihipStream_t* sparc_stream_t; /* == hipStream_t */
 
 #define SPARC_MAX_K 64
 /* per-row constants used by the per-step kernels, float[m][8] */
-#define SPARC_ROWC 8 /* {1/rho, g, d + cw, 1/sqrt(d), r, r2, c, c2} */
+#define SPARC_ROWC 8 /* {+-1/rho, S_ii, d + cw, 1/sqrt(d), r, r2, c, c2}; 1/rho < 0 flags an isolated row */
 
 int sparc_abi_version(void);
 
@@ -72,7 +72,7 @@ int sparc_csr_build(int64_t m, int64_t nnz_in, const int32_t* coords, const doub
  * {d = W 1, cw = W^T 1, rho}; coupling double[16] = {C row-major (9), m, s = 1^T A 1, ...}. */
 size_t sparc_affinity_prep_workspace_bytes(int64_t m, int64_t nnz);
 int sparc_affinity_prep(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* colidx,
-                        const float* val, const float* valT, float eps,
+                        const float* val, const float* valT, double eps,
                         float* rowc, float* vec, double* coupling,
                         void* ws, size_t ws_bytes, sparc_stream_t stream);
 

@@ -327,7 +327,7 @@ def affinity_prep_operator(A: sp.csr_matrix, eps: float = EPS_BACKGROUND) -> Dic
     St = sp.csr_matrix(S.T)
     x = 1.0 / rho
     cw = St @ x + V @ (C.T @ (U.T @ x)) - g * x
-    return {"r": r, "c": c, "r2": r2, "c2": c2, "s": s, "C": C, "g": g, "rho": rho, "d": d, "cw": cw}
+    return {"r": r, "c": c, "r2": r2, "c2": c2, "s": s, "C": C, "g": g, "sdiag": Sdiag, "rho": rho, "d": d, "cw": cw}
 
 
 def lap_forward_operator(A: sp.csr_matrix, prep: Dict[str, np.ndarray], Y: np.ndarray):

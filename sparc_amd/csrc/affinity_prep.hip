@@ -10,18 +10,51 @@ namespace {
 
 constexpr int PREP_W = 64;
 
-// r = A 1 and c = A^T 1 (row sums of val / valT)
-__global__ void rowsums(int64_t m, const int64_t* __restrict__ rowptr, const float* __restrict__ val,
-                        const float* __restrict__ valT, double* __restrict__ r, double* __restrict__ c) {
+// r = A 1 and c = A^T 1 (row sums of val / valT); iso[i] = 1 if row i has no off-diagonal entry
+__global__ void rowsums(int64_t m, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                        const float* __restrict__ val, const float* __restrict__ valT, double* __restrict__ r,
+                        double* __restrict__ c, double* __restrict__ iso) {
     const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
     if (i >= m) return;
     double a = 0.0, b = 0.0;
+    bool off = false;
     for (int64_t p = rowptr[i]; p < rowptr[i + 1]; ++p) {
         a += val[p];
         b += valT[p];
+        if (col[p] != i && (val[p] != 0.f || valT[p] != 0.f)) off = true;
     }
     r[i] = a;
     c[i] = b;
+    iso[i] = off ? 0.0 : 1.0;
+}
+
+// S_ii = A_ii + (A^2)_ii + (A^3)_ii in float64 straight from the definition (closed walks of
+// length 1..3); A_li is read from row i's mirrored values (the pattern is symmetric).
+__global__ void diag_of_s(int64_t m, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                          const float* __restrict__ val, const float* __restrict__ valT, double* __restrict__ sdiag) {
+    const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+    if (i >= m) return;
+    const int64_t b0 = rowptr[i], b1 = rowptr[i + 1];
+    double w1 = 0.0, w2 = 0.0, w3 = 0.0;
+    for (int64_t p = b0; p < b1; ++p) {
+        const int64_t j = col[p];
+        const double aij = val[p];
+        if (j == i) w1 = aij;
+        w2 += aij * static_cast<double>(valT[p]);
+        if (aij == 0.0) continue;
+        double inner = 0.0;  // sum_l A_jl A_li
+        for (int64_t q = rowptr[j]; q < rowptr[j + 1]; ++q) {
+            const int32_t l = col[q];
+            int64_t lo = b0, hi = b1;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (col[mid] < l) lo = mid + 1; else hi = mid;
+            }
+            if (lo < b1 && col[lo] == l) inner += static_cast<double>(val[q]) * static_cast<double>(valT[lo]);
+        }
+        w3 += aij * inner;
+    }
+    sdiag[i] = w1 + w2 + w3;
 }
 
 // y = add + M x with M given by (rowptr, col, v); add may be null
@@ -107,8 +140,8 @@ __global__ void prep_rows(int64_t m, const double* __restrict__ racc, const doub
                           const double* __restrict__ r2, const double* __restrict__ r3,
                           const double* __restrict__ c, const double* __restrict__ c2,
                           const double* __restrict__ scal, const double* __restrict__ coupling,
-                          double* __restrict__ rho, double* __restrict__ g, double* __restrict__ d,
-                          double* __restrict__ x) {
+                          const double* __restrict__ sdiag, double* __restrict__ rho, double* __restrict__ g,
+                          double* __restrict__ d, double* __restrict__ x) {
     const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
     if (i >= m) return;
     const double u[3] = {1.0, r[i], r2[i]};
@@ -130,11 +163,11 @@ __global__ void prep_rows(int64_t m, const double* __restrict__ racc, const doub
     double rr = a[0] + 2.0 * cross + low_sq;
     rr = rr > 0.0 ? sqrt(rr) : 0.0;
     rr = rr > 1e-12 ? rr : 1e-12;  // F.normalize(eps=1e-12) clamps the norm
-    const double gi = a[4] + low_diag;
+    const double gi = sdiag[i] + low_diag;
     rho[i] = rr;
     g[i] = gi;
     x[i] = 1.0 / rr;
-    d[i] = ((r[i] + r2[i] + r3[i]) + (uc[0] * vt1[0] + uc[1] * vt1[1] + uc[2] * vt1[2]) - gi) / rr;
+    d[i] = (((r[i] + r2[i] + r3[i]) - sdiag[i]) + ((uc[0] * vt1[0] + uc[1] * vt1[1] + uc[2] * vt1[2]) - low_diag)) / rr;
 }
 
 // utx = U^T x (3 sums)
@@ -150,7 +183,8 @@ __global__ void prep_finish(int64_t m, const double* __restrict__ chainT, const 
                             const double* __restrict__ coupling, const double* __restrict__ r,
                             const double* __restrict__ r2, const double* __restrict__ c, const double* __restrict__ c2,
                             const double* __restrict__ rho, const double* __restrict__ g, const double* __restrict__ d,
-                            const double* __restrict__ x, float* __restrict__ rowc, float* __restrict__ vec) {
+                            const double* __restrict__ x, const double* __restrict__ sdiag,
+                            const double* __restrict__ iso, float* __restrict__ rowc, float* __restrict__ vec) {
     const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
     if (i >= m) return;
     double ctu[3];  // C^T (U^T x)
@@ -158,8 +192,8 @@ __global__ void prep_finish(int64_t m, const double* __restrict__ chainT, const 
     for (int a = 0; a < 3; ++a) ctu[a] = coupling[a] * utx[0] + coupling[3 + a] * utx[1] + coupling[6 + a] * utx[2];
     const double cw = chainT[i] + (ctu[0] + c[i] * ctu[1] + c2[i] * ctu[2]) - g[i] * x[i];
     float* rc = rowc + i * SPARC_ROWC;
-    rc[0] = static_cast<float>(x[i]);
-    rc[1] = static_cast<float>(g[i]);
+    rc[0] = static_cast<float>(iso[i] != 0.0 ? -x[i] : x[i]);  // sign flags a row without off-diagonal entries
+    rc[1] = static_cast<float>(sdiag[i]);
     rc[2] = static_cast<float>(d[i] + cw);
     rc[3] = static_cast<float>(1.0 / sqrt(d[i]));
     rc[4] = static_cast<float>(r[i]);
@@ -176,7 +210,7 @@ struct PrepPlan {
 };
 size_t prep_bytes(int64_t m) {
     const size_t vd = sparc_align_up(static_cast<size_t>(m) * sizeof(double));
-    return 13 * vd + sparc_align_up(static_cast<size_t>(m) * 8 * sizeof(double)) +
+    return 14 * vd + sparc_align_up(static_cast<size_t>(m) * 8 * sizeof(double)) +
            2 * sparc_align_up(static_cast<size_t>(m) * PREP_W * sizeof(float)) + 2 * sparc_align_up(16 * sizeof(double));
 }
 
@@ -189,7 +223,7 @@ extern "C" size_t sparc_affinity_prep_workspace_bytes(int64_t m, int64_t nnz) {
 }
 
 extern "C" int sparc_affinity_prep(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* colidx,
-                                   const float* val, const float* valT, float eps, float* rowc, float* vec,
+                                   const float* val, const float* valT, double eps, float* rowc, float* vec,
                                    double* coupling, void* ws, size_t ws_bytes, sparc_stream_t stream) {
     if (m <= 0 || nnz < 0 || !rowptr || !rowc || !vec || !coupling || (nnz > 0 && (!colidx || !val))) return SPARC_ERR_ARG;
     const float* vT = valT ? valT : val;
@@ -206,8 +240,8 @@ extern "C" int sparc_affinity_prep(int64_t m, int64_t nnz, const int64_t* rowptr
     double* t1 = cv.take<double>(m);
     double* t2 = cv.take<double>(m);
     double* chainT = cv.take<double>(m);
-    double* spare = cv.take<double>(m);
-    (void)spare;
+    double* iso = cv.take<double>(m);
+    double* sdiag = cv.take<double>(m);
     double* racc = cv.take<double>(static_cast<size_t>(m) * 8);
     float* P1 = cv.take<float>(static_cast<size_t>(m) * PREP_W);
     float* P2 = cv.take<float>(static_cast<size_t>(m) * PREP_W);
@@ -216,11 +250,12 @@ extern "C" int sparc_affinity_prep(int64_t m, int64_t nnz, const int64_t* rowptr
     if (!ws || !cv.ok()) return SPARC_ERR_WS;
 
     const dim3 bt(256), gt(static_cast<unsigned>((m + 255) / 256));
-    hipLaunchKernelGGL(rowsums, gt, bt, 0, stream, m, rowptr, val, vT, r, c);
+    hipLaunchKernelGGL(rowsums, gt, bt, 0, stream, m, rowptr, colidx, val, vT, r, c, iso);
+    hipLaunchKernelGGL(diag_of_s, gt, bt, 0, stream, m, rowptr, colidx, val, vT, sdiag);
     hipLaunchKernelGGL(spmv64, gt, bt, 0, stream, m, rowptr, colidx, val, r, static_cast<const double*>(nullptr), r2);
     hipLaunchKernelGGL(spmv64, gt, bt, 0, stream, m, rowptr, colidx, vT, c, static_cast<const double*>(nullptr), c2);
     hipLaunchKernelGGL(spmv64, gt, bt, 0, stream, m, rowptr, colidx, val, r2, static_cast<const double*>(nullptr), r3);
-    hipLaunchKernelGGL(prep_scalars, dim3(1), bt, 0, stream, m, static_cast<double>(eps), r, c, c2, scal, coupling);
+    hipLaunchKernelGGL(prep_scalars, dim3(1), bt, 0, stream, m, eps, r, c, c2, scal, coupling);
     SPARC_CHECK_LAUNCH();
 
     if (hipMemsetAsync(racc, 0, static_cast<size_t>(m) * 8 * sizeof(double), stream) != hipSuccess) return SPARC_ERR_LAUNCH;
@@ -238,13 +273,13 @@ extern "C" int sparc_affinity_prep(int64_t m, int64_t nnz, const int64_t* rowptr
         rc = sparc_spmm_launch(EPI_PREP_ACC, PREP_W, a, stream);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(prep_rows, gt, bt, 0, stream, m, racc, r, r2, r3, c, c2, scal, coupling, rho, g, d, x);
+    hipLaunchKernelGGL(prep_rows, gt, bt, 0, stream, m, racc, r, r2, r3, c, c2, scal, coupling, sdiag, rho, g, d, x);
     hipLaunchKernelGGL(prep_utx, dim3(1), bt, 0, stream, m, r, r2, x, utx);
     // chainT = A^T (x + A^T (x + A^T x))
     hipLaunchKernelGGL(spmv64, gt, bt, 0, stream, m, rowptr, colidx, vT, x, x, t1);
     hipLaunchKernelGGL(spmv64, gt, bt, 0, stream, m, rowptr, colidx, vT, t1, x, t2);
     hipLaunchKernelGGL(spmv64, gt, bt, 0, stream, m, rowptr, colidx, vT, t2, static_cast<const double*>(nullptr), chainT);
-    hipLaunchKernelGGL(prep_finish, gt, bt, 0, stream, m, chainT, utx, coupling, r, r2, c, c2, rho, g, d, x, rowc, vec);
+    hipLaunchKernelGGL(prep_finish, gt, bt, 0, stream, m, chainT, utx, coupling, r, r2, c, c2, rho, g, d, x, sdiag, iso, rowc, vec);
     SPARC_CHECK_LAUNCH();
     return SPARC_OK;
 }

@@ -112,22 +112,30 @@ __global__ __launch_bounds__(256) void spmm_rows(const SpmmArgs a) {
                 r[0] += ss; r[1] += s0; r[2] += s1; r[3] += s2; r[4] += sd;
             }
         } else {  // EPI_LAP_SINGLE / EPI_LAP_DUAL
-            const float4 rc0 = *reinterpret_cast<const float4*>(a.rowc + row * SPARC_ROWC);      // 1/rho, g, d+cw, 1/sqrt(d)
-            const float4 rc1 = *reinterpret_cast<const float4*>(a.rowc + row * SPARC_ROWC + 4);  // r, r2, c, c2
+            // rowc: {+-1/rho, S_ii, d+cw, 1/sqrt(d)}, {r, r2, c, c2}; a negative 1/rho marks a row without
+            // off-diagonal entries, whose chain result is exactly S_ii x and is dropped instead of cancelled
+            const float4 rc0 = *reinterpret_cast<const float4*>(a.rowc + row * SPARC_ROWC);
+            const float4 rc1 = *reinterpret_cast<const float4*>(a.rowc + row * SPARC_ROWC + 4);
             const float4 x0 = *reinterpret_cast<const float4*>(a.X0 + ro);
+            const bool isolated = rc0.x < 0.f;
+            const float irho = fabsf(rc0.x);
             const bool right = DUAL && lr >= HALF;
             const int KP = DUAL ? W / 2 : W;
             const int cl = (DUAL ? (lr % HALF) : lr) * 4;
             const float* Mb = a.M12 + (right ? 3 * KP : 0) + cl;
+            const float* Cf = a.M12 + 6 * KP;  // the 3x3 coupling, row-major
+            // diagonal of U C V^T for this row
+            const float ldiag = (Cf[0] + Cf[1] * rc1.z + Cf[2] * rc1.w) + rc1.x * (Cf[3] + Cf[4] * rc1.z + Cf[5] * rc1.w) +
+                                rc1.y * (Cf[6] + Cf[7] * rc1.z + Cf[8] * rc1.w);
             const float u1 = right ? rc1.z : rc1.x, u2 = right ? rc1.w : rc1.y;
             const float4 ma = *reinterpret_cast<const float4*>(Mb);
             const float4 mb = *reinterpret_cast<const float4*>(Mb + KP);
             const float4 mc = *reinterpret_cast<const float4*>(Mb + 2 * KP);
             float4 t;
-            t.x = acc.x + (ma.x + u1 * mb.x + u2 * mc.x) - rc0.y * x0.x;
-            t.y = acc.y + (ma.y + u1 * mb.y + u2 * mc.y) - rc0.y * x0.y;
-            t.z = acc.z + (ma.z + u1 * mb.z + u2 * mc.z) - rc0.y * x0.z;
-            t.w = acc.w + (ma.w + u1 * mb.w + u2 * mc.w) - rc0.y * x0.w;
+            t.x = (isolated ? 0.f : acc.x - rc0.y * x0.x) + ((ma.x + u1 * mb.x + u2 * mc.x) - ldiag * x0.x);
+            t.y = (isolated ? 0.f : acc.y - rc0.y * x0.y) + ((ma.y + u1 * mb.y + u2 * mc.y) - ldiag * x0.y);
+            t.z = (isolated ? 0.f : acc.z - rc0.y * x0.z) + ((ma.z + u1 * mb.z + u2 * mc.z) - ldiag * x0.z);
+            t.w = (isolated ? 0.f : acc.w - rc0.y * x0.w) + ((ma.w + u1 * mb.w + u2 * mc.w) - ldiag * x0.w);
             float4 wt = make_float4(0.f, 0.f, 0.f, 0.f);
             if (DUAL) {  // W^T Yn sits HALF lanes to the right of W Yn
                 wt.x = __shfl(t.x, lane + HALF);
@@ -137,7 +145,7 @@ __global__ __launch_bounds__(256) void spmm_rows(const SpmmArgs a) {
             }
             double dot = 0.0;
             if (g == 0 && !right) {
-                const float4 wy = make_float4(rc0.x * t.x, rc0.x * t.y, rc0.x * t.z, rc0.x * t.w);
+                const float4 wy = make_float4(irho * t.x, irho * t.y, irho * t.z, irho * t.w);
                 const float hd = 0.5f * rc0.z;
                 const float ly0 = hd * x0.x - wy.x, ly1 = hd * x0.y - wy.y, ly2 = hd * x0.z - wy.z, ly3 = hd * x0.w - wy.w;
                 dot = static_cast<double>(x0.x) * ly0 + static_cast<double>(x0.y) * ly1 +
@@ -186,7 +194,7 @@ __global__ __launch_bounds__(256) void lap_scale(int64_t m, int k, int64_t ldy, 
         s[1] += rc1.z * y;
         s[2] += rc1.w * y;
         if (DUAL) {
-            const float x2 = y * rc0.x;
+            const float x2 = y * fabsf(rc0.x);
             X[r * W + KP + col] = x2;
             s[3] += x2;
             s[4] += rc1.x * x2;
@@ -228,6 +236,7 @@ __global__ void lap_colsum_finish(int KP, int nparts, bool dual, const float* __
         }
         M12[q * KP + col] = static_cast<float>(t);
     }
+    if (threadIdx.x < 9) M12[6 * KP + threadIdx.x] = static_cast<float>(coupling[threadIdx.x]);
 }
 
 __global__ __launch_bounds__(256) void loss_finish(int64_t n, const double* __restrict__ part, double scale,
@@ -324,7 +333,7 @@ LapPlan lap_plan(int64_t m, int k) {
     p.nloss = sparc_rows_blocks(m);
     p.bytes = 3 * sparc_align_up(static_cast<size_t>(m) * p.W * sizeof(float)) +
               sparc_align_up(static_cast<size_t>(SCALE_MAX_BLOCKS) * 6 * p.kp * sizeof(float)) +
-              sparc_align_up(6 * SPARC_MAX_K * sizeof(float)) +
+              sparc_align_up((6 * SPARC_MAX_K + 16) * sizeof(float)) +
               sparc_align_up(static_cast<size_t>(p.nloss > 0 ? p.nloss : 1) * sizeof(double));
     return p;
 }
@@ -350,7 +359,7 @@ extern "C" int sparc_lap_fwd(int64_t m, int64_t nnz, const int64_t* rowptr, cons
     float* P1 = c.take<float>(static_cast<size_t>(m) * p.W);
     float* P2 = c.take<float>(static_cast<size_t>(m) * p.W);
     float* colpart = c.take<float>(static_cast<size_t>(SCALE_MAX_BLOCKS) * 6 * p.kp);
-    float* M12 = c.take<float>(6 * SPARC_MAX_K);
+    float* M12 = c.take<float>(6 * SPARC_MAX_K + 16);
     double* loss_part = c.take<double>(static_cast<size_t>(p.nloss));
     if (!ws || !c.ok()) return SPARC_ERR_WS;
 
