@@ -38,6 +38,8 @@ _SIGS = {
     "sparc_lap_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "sparc_lap_fwd": (c_int, [c_int64, c_int64, P, P, P, P, P, P, c_int, c_int64, P, P, P, P, c_size_t, P]),
     "sparc_spmm": (c_int, [c_int64, c_int64, P, P, P, c_int, P, P, P, P]),
+    "sparc_profile_begin": (c_int, [c_int, c_int]),
+    "sparc_profile_end": (c_int, [P, P]),
     "sparc_gram_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "sparc_gram": (c_int, [c_int64, c_int, P, c_int64, P, c_int64, P, P, c_size_t, P]),
     "sparc_orth_weights": (c_int, [c_int64, c_int, P, P, c_int64, P, c_int, P, P, P, P, P, P]),

@@ -10,6 +10,8 @@
 // In "dual" mode X is [Yn | Yn/rho]: the left half is multiplied by A (val), the
 // right half by A^T (valT, same pattern), so the forward product W Yn and the
 // backward product W^T Yn share one pass over the index stream.
+#include <vector>
+
 #include "spmm.h"
 
 namespace {
@@ -253,12 +255,25 @@ __global__ __launch_bounds__(256) void loss_finish(int64_t n, const double* __re
     if (threadIdx.x == 0) *loss = sm[0] * scale;
 }
 
+// Optional timing of one kernel class with HIP events recorded on the launch stream.
+struct Profiler {
+    int epi = -1;                 // which epilogue class is timed
+    std::vector<hipEvent_t> ev;   // start/stop pairs
+    size_t used = 0;
+} g_prof;
+
 template <int LR, bool DUAL, int EPI>
 int launch_rows(const SpmmArgs& a, hipStream_t stream) {
     const int64_t nb = (a.m + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
     if (nb <= 0) return SPARC_OK;
     if (nb > 0x7fffffffLL) return SPARC_ERR_ARG;
+    const bool timed = g_prof.epi == EPI && g_prof.used + 2 <= g_prof.ev.size();
+    if (timed) (void)hipEventRecord(g_prof.ev[g_prof.used], stream);
     hipLaunchKernelGGL((spmm_rows<LR, DUAL, EPI>), dim3(static_cast<unsigned>(nb)), dim3(256), 0, stream, a);
+    if (timed) {
+        (void)hipEventRecord(g_prof.ev[g_prof.used + 1], stream);
+        g_prof.used += 2;
+    }
     SPARC_CHECK_LAUNCH();
     return SPARC_OK;
 }
@@ -298,6 +313,36 @@ int sparc_spmm_launch(int epi, int width, const SpmmArgs& a, hipStream_t stream)
         case EPI_PREP_ACC: return width == 64 ? launch_rows<16, false, EPI_PREP_ACC>(a, stream) : SPARC_ERR_ARG;
     }
     return SPARC_ERR_ARG;
+}
+
+extern "C" int sparc_profile_begin(int epilogue, int max_launches) {
+    if (max_launches < 0 || epilogue < 0 || epilogue > EPI_PREP_ACC) return SPARC_ERR_ARG;
+    for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
+    g_prof.ev.assign(static_cast<size_t>(max_launches) * 2, nullptr);
+    for (auto& e : g_prof.ev)
+        if (hipEventCreate(&e) != hipSuccess) return SPARC_ERR_LAUNCH;
+    g_prof.used = 0;
+    g_prof.epi = epilogue;
+    return SPARC_OK;
+}
+
+extern "C" int sparc_profile_end(double* total_ms, int64_t* launches) {
+    double total = 0.0;
+    int64_t n = 0;
+    for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+        float ms = 0.f;
+        if (hipEventSynchronize(g_prof.ev[i + 1]) != hipSuccess) return SPARC_ERR_LAUNCH;
+        if (hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]) != hipSuccess) return SPARC_ERR_LAUNCH;
+        total += ms;
+        ++n;
+    }
+    for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
+    g_prof.ev.clear();
+    g_prof.used = 0;
+    g_prof.epi = -1;
+    if (total_ms) *total_ms = total;
+    if (launches) *launches = n;
+    return SPARC_OK;
 }
 
 extern "C" int sparc_spmm(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* colidx, const float* val,

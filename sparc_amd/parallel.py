@@ -1,0 +1,102 @@
+"""Cluster batches sharded over the GPUs of one node: one process per GPU, the MLP
+replicated, every rank training on its own batches, and one collective per step, the
+all-reduce of the flat MLP gradient (RCCL over xGMI through torch.distributed).
+
+The reference is single-device (src/SpectralNet.py:21); its batches are independent
+units (each support is the induced sub-block of its own nodes, src/utils.py:83), which
+is what makes this sharding exact per batch.  With P ranks one optimiser step averages
+the gradients of P batches; at P = 1 it is the reference's step.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_batches(n_batches: int, world_size: int, rank: int) -> List[int]:
+    """Round-robin ownership: batch b lives on rank b % world_size."""
+    if not 0 <= rank < world_size:
+        raise ValueError("rank out of range")
+    return list(range(rank, n_batches, world_size))
+
+
+class FlatGradients:
+    """All parameter gradients as views into one contiguous buffer, so that the per-step
+    collective is a single all-reduce over one bucket (6-8 MB for the SpectralNet MLP)."""
+
+    def __init__(self, params: Sequence[torch.nn.Parameter]):
+        self.params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        ref = self.params[0]
+        self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce_mean(self, group=None):
+        if dist.is_available() and dist.is_initialized():
+            ws = dist.get_world_size(group)
+            if ws > 1:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+                self.flat.div_(ws)
+
+
+class ShardedSpectralTrainer:
+    """Data-parallel SpectralNet steps over this rank's shard of cluster batches."""
+
+    def __init__(self, architecture: dict, input_dim: int, device, lr: float = 1e-3, orth_mode: str = "reference",
+                 group=None, seed: Optional[int] = 0):
+        from .SpectralTrainer import SpectralNetLoss, SpectralNetModel
+        self.device = torch.device(device)
+        if seed is not None:
+            torch.manual_seed(seed)  # identical initial weights on every rank
+        self.net = SpectralNetModel(architecture, input_dim, self.device, orth_mode=orth_mode).to(self.device)
+        self.k = architecture["output_dim"]
+        self.group = group
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            for p in self.net.parameters():
+                dist.broadcast(p.data, src=0, group=group)
+        self.grads = FlatGradients(list(self.net.parameters()))
+        self.optimizer = torch.optim.Adam(self.net.parameters(), lr=lr)
+        self.criterion = SpectralNetLoss()
+        self.features = []
+        self.batches = []
+
+    def add_batch(self, features: torch.Tensor, batch) -> int:
+        self.features.append(features.to(self.device, dtype=torch.float32).contiguous())
+        self.batches.append(batch)
+        return len(self.batches) - 1
+
+    def step(self, pid: int, pid_2: int, top_idx=None) -> torch.Tensor:
+        """Orthogonality step on local batch pid_2, gradient step on local batch pid
+        (src/SpectralTrainer.py:216-238), gradient averaged over the ranks before Adam."""
+        net = self.net
+        net.eval()
+        net(self.features[pid_2], should_update_orth_weights=True, top_idx=top_idx)
+        net.train()
+        self.grads.zero()
+        Y = net(self.features[pid], should_update_orth_weights=False)
+        loss = self.criterion(self.batches[pid], Y, is_normalized=True)
+        loss.backward()
+        self.grads.all_reduce_mean(self.group)
+        self.optimizer.step()
+        return loss.detach()
+
+    @torch.no_grad()
+    def validation_loss(self, features: Sequence[torch.Tensor], batches: Sequence) -> torch.Tensor:
+        """Sum of the validation losses of this rank's validation batches, summed over the ranks."""
+        self.net.eval()
+        total = torch.zeros((), dtype=torch.float64, device=self.device)
+        for x, b in zip(features, batches):
+            Y = self.net(x.to(self.device), should_update_orth_weights=False)
+            total += self.criterion(b, Y, is_normalized=True)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            dist.all_reduce(total, group=self.group)
+        return total

@@ -1,0 +1,78 @@
+"""Synthetic graphs of the reference's dataset shapes (planted clusters), generated on the
+device.  There is no network for the real datasets; cluster membership is planted (the
+reference obtains it from METIS, src/partition_utils.py:56, which is an input of the path).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .utils import DeviceGraph
+
+SHAPES = {
+    # name: nodes, undirected edges, METIS clusters, clusters per batch, feature dim, k, diag_lambda
+    "cora": dict(n=2708, edges=5278, clusters=1, bsize=1, din=32, k=64, diag_lambda=-1),
+    "pubmed": dict(n=19717, edges=44338, clusters=15, bsize=5, din=500, k=32, diag_lambda=-1),
+    "reddit": dict(n=232965, edges=57_000_000, clusters=1500, bsize=50, din=256, k=64, diag_lambda=-1),
+    "amazon2m": dict(n=2449029, edges=61859140, clusters=5000, bsize=50, din=10, k=47, diag_lambda=0.01),
+}
+
+
+def planted_cluster_graph(n: int, n_edges: int, n_clusters: int, device, frac_in_cluster: float = 0.7,
+                          skew: float = 2.0, seed: int = 0):
+    """Symmetric adjacency A + A^T + I (values 1, unit diagonal, as src/utils.py:238-243 builds it)
+    with `frac_in_cluster` of the edges inside contiguous node ranges (the planted clusters) and
+    the rest uniform; `skew` > 1 concentrates endpoints on the first nodes of a cluster
+    (heavier-tailed degrees).  Returns (DeviceGraph, bounds int64[n_clusters+1])."""
+    dev = torch.device(device)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    bounds = torch.div(torch.arange(n_clusters + 1, device=dev, dtype=torch.int64) * n, n_clusters, rounding_mode="floor")
+    e_in = int(n_edges * frac_in_cluster)
+    e_out = n_edges - e_in
+    c = torch.randint(n_clusters, (e_in,), generator=gen, device=dev)
+    lo = bounds[c]
+    sz = (bounds[c + 1] - lo).double()
+    u = lo + (torch.rand(e_in, generator=gen, device=dev, dtype=torch.float64).pow(skew) * sz).long()
+    v = lo + (torch.rand(e_in, generator=gen, device=dev, dtype=torch.float64).pow(skew) * sz).long()
+    uo = torch.randint(n, (e_out,), generator=gen, device=dev)
+    vo = torch.randint(n, (e_out,), generator=gen, device=dev)
+    u = torch.cat([u, uo]).clamp_(max=n - 1)
+    v = torch.cat([v, vo]).clamp_(max=n - 1)
+    del uo, vo, c, lo, sz
+    keep = u != v
+    u, v = u[keep], v[keep]
+    diag = torch.arange(n, device=dev, dtype=torch.int64)
+    keys = torch.cat([u * n + v, v * n + u, diag * n + diag])
+    del u, v, keep
+    keys = torch.unique(keys)  # sorted, duplicates dropped
+    rows = torch.div(keys, n, rounding_mode="floor")
+    cols = (keys - rows * n).to(torch.int32)
+    counts = torch.bincount(rows, minlength=n)
+    indptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    indptr[1:] = torch.cumsum(counts, 0)
+    data = torch.ones(cols.numel(), dtype=torch.float64, device=dev)
+    return DeviceGraph(n, indptr, cols.contiguous(), data), bounds
+
+
+def cluster_batches(bounds: torch.Tensor, bsize: int, seed: int = 0):
+    """Node lists of the training batches: the clusters are shuffled (np.random.shuffle in
+    src/utils.py:75) and concatenated `bsize` at a time (:76-80)."""
+    b = bounds.cpu().numpy()
+    n_clusters = len(b) - 1
+    order = np.random.RandomState(seed).permutation(n_clusters)
+    batches = []
+    for st in range(0, n_clusters, bsize):
+        ids = order[st:st + bsize]
+        batches.append(np.concatenate([np.arange(b[c], b[c + 1], dtype=np.int32) for c in ids]))
+    return batches
+
+
+def block_features(node_ids: np.ndarray, bounds: torch.Tensor, din: int, n_blocks: int, seed: int = 0) -> torch.Tensor:
+    """N(0,1) features plus a per-block mean shift (block = cluster id mod n_blocks)."""
+    b = bounds.cpu().numpy()
+    cluster = np.searchsorted(b, node_ids, side="right") - 1
+    block = cluster % n_blocks
+    means = np.random.RandomState(seed + 1).standard_normal((n_blocks, din)).astype(np.float32)
+    rng = np.random.RandomState(seed + 2 + int(node_ids[0]))
+    return torch.from_numpy(means[block] + rng.standard_normal((len(node_ids), din)).astype(np.float32))

@@ -1,0 +1,84 @@
+"""world_size-2 CPU (gloo) tests of the data-parallel plumbing: batch sharding and the
+flat-gradient all-reduce.  The kernels need a GPU; here a plain torch MLP stands in so that
+the collective logic is exercised end to end."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from sparc_amd.parallel import FlatGradients, shard_batches
+
+
+def test_shard_batches_partition():
+    for n, w in [(100, 8), (7, 2), (3, 4), (0, 2)]:
+        seen = sorted(b for r in range(w) for b in shard_batches(n, w, r))
+        assert seen == list(range(n))
+        sizes = [len(shard_batches(n, w, r)) for r in range(w)]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_batches(4, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+    flat = FlatGradients(list(net.parameters()))
+    opt = torch.optim.Adam(net.parameters(), lr=1e-2)
+    g = torch.Generator().manual_seed(100 + rank)      # every rank: its own batch
+    x = torch.randn(16, 5, generator=g)
+    for _ in range(3):
+        flat.zero()
+        net(x).pow(2).sum().backward()
+        local = flat.flat.clone()
+        flat.all_reduce_mean()
+        opt.step()
+    gathered = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    params = torch.cat([p.detach().flatten() for p in net.parameters()])
+    allp = [torch.zeros_like(params) for _ in range(world)]
+    dist.all_gather(allp, params)
+    if rank == 0:
+        out.put((torch.stack(gathered).mean(0).numpy(), flat.flat.clone().numpy(), torch.stack(allp).numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_all_reduce_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    mean_local, reduced, params = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.allclose(mean_local, reduced, atol=1e-6)             # the collective averaged the ranks' gradients
+    assert np.array_equal(params[0], params[1])                    # replicas stayed identical after Adam
+    assert np.abs(reduced).sum() > 0
+
+
+def test_flat_gradients_views_single_process():
+    net = torch.nn.Linear(4, 2)
+    flat = FlatGradients(list(net.parameters()))
+    net(torch.ones(3, 4)).sum().backward()
+    assert flat.flat.data_ptr() == net.weight.grad.data_ptr()
+    assert torch.allclose(flat.flat[:8].view(2, 4), torch.full((2, 4), 3.0))
+    flat.zero()
+    assert net.weight.grad.abs().sum() == 0
+    flat.all_reduce_mean()   # no process group: a no-op
