@@ -83,10 +83,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
+    # rehearsal knobs for a one-GPU box: several ranks on one card over gloo (never used by the driver)
+    backend = os.environ.get("SPARC_BENCH_BACKEND", "nccl")
+    if "SPARC_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["SPARC_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from sparc_amd import synth
@@ -159,7 +166,7 @@ def main():
     tot_ms, launches = ctypes.c_double(0.0), ctypes.c_int64(0)
     check(lib.sparc_profile_end(ctypes.byref(tot_ms), ctypes.byref(launches)), "sparc_profile_end")
 
-    stats = torch.tensor([elapsed, float(nodes)], dtype=torch.float64, device=dev)
+    stats = torch.tensor([elapsed, float(nodes)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)

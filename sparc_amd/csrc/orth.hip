@@ -7,7 +7,7 @@ namespace {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-constexpr int GRAM_MAX_BLOCKS = 256;
+constexpr int GRAM_MAX_BLOCKS = 128;
 
 // G_b = P[rows of block b]^T Q[rows of block b], accumulated in float64 by
 // v_mfma_f64_16x16x4_f64.  Lane l feeds A[i = l&15][kk = l>>4] = P[r0+kk][16 ti + i] and
@@ -69,9 +69,16 @@ __global__ __launch_bounds__(256) void gram_partial(int64_t m, int k, const floa
 __global__ void gram_reduce(int kk, int nparts, const double* __restrict__ slab, double* __restrict__ G) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= kk) return;
-    double t = 0.0;
-    for (int b = 0; b < nparts; ++b) t += slab[static_cast<int64_t>(b) * kk + e];
-    G[e] = t;
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;  // four independent chains, fixed order
+    int b = 0;
+    for (; b + 4 <= nparts; b += 4) {
+        t0 += slab[static_cast<int64_t>(b) * kk + e];
+        t1 += slab[static_cast<int64_t>(b + 1) * kk + e];
+        t2 += slab[static_cast<int64_t>(b + 2) * kk + e];
+        t3 += slab[static_cast<int64_t>(b + 3) * kk + e];
+    }
+    for (; b < nparts; ++b) t0 += slab[static_cast<int64_t>(b) * kk + e];
+    G[e] = (t0 + t1) + (t2 + t3);
 }
 
 // Single workgroup.  LDS images: R (Gram, then its Cholesky factor, upper), X = R^-1, Q.
@@ -226,13 +233,14 @@ __global__ __launch_bounds__(256) void orth_weights_bwd_kernel(int64_t m, int k,
     }
 }
 
-// Z[rows] = Yt[rows] Wo  (or Wo^T).  64 rows per block; thread (r, cg) owns KP/4 columns.
+// Z[rows] = Yt[rows] Wo  (or Wo^T).  64 rows per block; thread (tr, tc) owns the 4 x 4 outputs
+// rows 4 tr.., columns 4 tc.. and walks the inner dimension with one 16-byte LDS read of Wo per step.
 template <int KP>
 __global__ __launch_bounds__(256) void orth_apply_kernel(int64_t m, int k, const float* __restrict__ Yt, int64_t ld,
                                                          const float* __restrict__ Wo, int transpose_w,
                                                          float* __restrict__ Z, int64_t ldz) {
-    constexpr int CT = KP / 4;  // columns per thread
-    __shared__ float Ws[KP][KP];
+    constexpr int TC = KP / 4;
+    __shared__ __attribute__((aligned(16))) float Ws[KP][KP];
     __shared__ float Ys[64][KP + 1];
     const int tid = threadIdx.x;
     for (int e = tid; e < KP * KP; e += 256) {
@@ -248,21 +256,34 @@ __global__ __launch_bounds__(256) void orth_apply_kernel(int64_t m, int k, const
         Ys[r][c] = (row < m && c < k) ? Yt[row * ld + c] : 0.f;
     }
     __syncthreads();
-    const int r = tid >> 2, cg = tid & 3;
-    float acc[CT];
+    if (tid >= 16 * TC) return;
+    const int tr = tid / TC, tc = tid % TC;
+    float acc[4][4];
 #pragma unroll
-    for (int q = 0; q < CT; ++q) acc[q] = 0.f;
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+#pragma unroll 4
     for (int l = 0; l < KP; ++l) {
-        const float y = Ys[r][l];
+        const float4 w = *reinterpret_cast<const float4*>(&Ws[l][4 * tc]);
+        const float y[4] = {Ys[4 * tr][l], Ys[4 * tr + 1][l], Ys[4 * tr + 2][l], Ys[4 * tr + 3][l]};
 #pragma unroll
-        for (int q = 0; q < CT; ++q) acc[q] = fmaf(y, Ws[l][cg * CT + q], acc[q]);
+        for (int i = 0; i < 4; ++i) {
+            acc[i][0] = fmaf(y[i], w.x, acc[i][0]);
+            acc[i][1] = fmaf(y[i], w.y, acc[i][1]);
+            acc[i][2] = fmaf(y[i], w.z, acc[i][2]);
+            acc[i][3] = fmaf(y[i], w.w, acc[i][3]);
+        }
     }
-    const int64_t row = r0 + r;
-    if (row < m) {
 #pragma unroll
-        for (int q = 0; q < CT; ++q) {
-            const int c = cg * CT + q;
-            if (c < k) Z[row * ldz + c] = acc[q];
+    for (int i = 0; i < 4; ++i) {
+        const int64_t row = r0 + 4 * tr + i;
+        if (row < m) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = 4 * tc + j;
+                if (c < k) Z[row * ldz + c] = acc[i][j];
+            }
         }
     }
 }

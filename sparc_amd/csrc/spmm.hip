@@ -16,7 +16,35 @@
 
 namespace {
 
-constexpr int ROWS_PER_BLOCK = 16;
+constexpr int ROWS_PER_BLOCK = 4;  // one row per wave
+
+// U gathers in flight: the U rows of X are requested before the first is consumed.
+template <int LR, bool DUAL, int U>
+__device__ __forceinline__ void gather_rows(float4& acc, const int c, const float v, const float vt, const int it,
+                                            const int g, const int lr, const float* __restrict__ Xg) {
+    constexpr int W = LR * 4, G = 64 / LR, HALF = LR / 2;
+    float4 x[U];
+    float w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int idx = (it + u) * G + g;
+        const int cj = __shfl(c, idx);
+        float vj = __shfl(v, idx);
+        if (DUAL) {
+            const float vtj = __shfl(vt, idx);
+            vj = (lr >= HALF) ? vtj : vj;
+        }
+        w[u] = vj;
+        x[u] = *reinterpret_cast<const float4*>(Xg + static_cast<int64_t>(cj) * W + lr * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        acc.x = fmaf(w[u], x[u].x, acc.x);
+        acc.y = fmaf(w[u], x[u].y, acc.y);
+        acc.z = fmaf(w[u], x[u].z, acc.z);
+        acc.w = fmaf(w[u], x[u].w, acc.w);
+    }
+}
 
 template <int LR, bool DUAL, int EPI>
 __global__ __launch_bounds__(256) void spmm_rows(const SpmmArgs a) {
@@ -45,22 +73,13 @@ __global__ __launch_bounds__(256) void spmm_rows(const SpmmArgs a) {
             // idle lanes point at a row that is read anyway and carry a zero weight
             const int c_first = __shfl(c, 0);
             if (lane >= cnt) c = c_first;
-            const int iters = (cnt + G - 1) / G;
-#pragma unroll 4
-            for (int it = 0; it < iters; ++it) {
-                const int idx = it * G + g;
-                const int cj = __shfl(c, idx);
-                float vj = __shfl(v, idx);
-                if (DUAL) {
-                    const float vtj = __shfl(vt, idx);
-                    vj = (lr >= HALF) ? vtj : vj;
-                }
-                const float4 x = *reinterpret_cast<const float4*>(a.Xg + static_cast<int64_t>(cj) * W + lr * 4);
-                acc.x = fmaf(vj, x.x, acc.x);
-                acc.y = fmaf(vj, x.y, acc.y);
-                acc.z = fmaf(vj, x.z, acc.z);
-                acc.w = fmaf(vj, x.w, acc.w);
-            }
+            const int iters = (cnt + G - 1) / G;  // wave-uniform; (iters - 1) * G + g <= 63
+            int it = 0;
+            if (G <= 8)
+                for (; it + 8 <= iters; it += 8) gather_rows<LR, DUAL, 8>(acc, c, v, vt, it, g, lr, a.Xg);
+            if (it + 4 <= iters) { gather_rows<LR, DUAL, 4>(acc, c, v, vt, it, g, lr, a.Xg); it += 4; }
+            if (it + 2 <= iters) { gather_rows<LR, DUAL, 2>(acc, c, v, vt, it, g, lr, a.Xg); it += 2; }
+            if (it < iters) gather_rows<LR, DUAL, 1>(acc, c, v, vt, it, g, lr, a.Xg);
         }
 #pragma unroll
         for (int off = LR; off < 64; off <<= 1) {
@@ -224,9 +243,16 @@ __global__ void lap_colsum_finish(int KP, int nparts, bool dual, const float* __
     const int q = threadIdx.x / KP, col = threadIdx.x % KP;
     const int ns = dual ? 6 : 3;
     if (q < ns) {
-        double t = 0.0;
-        for (int b = 0; b < nparts; ++b) t += colpart[(static_cast<int64_t>(b) * 6 + q) * KP + col];
-        S[q][col] = t;
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;  // four independent chains, fixed order
+        int b = 0;
+        for (; b + 4 <= nparts; b += 4) {
+            t0 += colpart[(static_cast<int64_t>(b) * 6 + q) * KP + col];
+            t1 += colpart[(static_cast<int64_t>(b + 1) * 6 + q) * KP + col];
+            t2 += colpart[(static_cast<int64_t>(b + 2) * 6 + q) * KP + col];
+            t3 += colpart[(static_cast<int64_t>(b + 3) * 6 + q) * KP + col];
+        }
+        for (; b < nparts; ++b) t0 += colpart[(static_cast<int64_t>(b) * 6 + q) * KP + col];
+        S[q][col] = (t0 + t1) + (t2 + t3);
     }
     __syncthreads();
     if (q < ns) {
@@ -355,7 +381,7 @@ extern "C" int sparc_spmm(int64_t m, int64_t nnz, const int64_t* rowptr, const i
 }
 
 namespace {
-constexpr int SCALE_MAX_BLOCKS = 1024;
+constexpr int SCALE_MAX_BLOCKS = 128;
 struct LapPlan {
     int kp, W;
     int64_t nscale, rows_per_block, nloss;

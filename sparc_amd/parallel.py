@@ -16,6 +16,30 @@ import torch
 import torch.distributed as dist
 
 
+def _staged(t: torch.Tensor, group) -> bool:
+    """gloo cannot reduce device tensors reliably: rehearsals of the multi-rank path on a GPU
+    stage through the host (RCCL, the production backend, reduces in place)."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def all_reduce_sum(t: torch.Tensor, group=None):
+    if _staged(t, group):
+        host = t.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
+def broadcast(t: torch.Tensor, src: int = 0, group=None):
+    if _staged(t, group):
+        host = t.cpu()
+        dist.broadcast(host, src=src, group=group)
+        t.copy_(host)
+    else:
+        dist.broadcast(t, src=src, group=group)
+
+
 def shard_batches(n_batches: int, world_size: int, rank: int) -> List[int]:
     """Round-robin ownership: batch b lives on rank b % world_size."""
     if not 0 <= rank < world_size:
@@ -44,7 +68,7 @@ class FlatGradients:
         if dist.is_available() and dist.is_initialized():
             ws = dist.get_world_size(group)
             if ws > 1:
-                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+                all_reduce_sum(self.flat, group)
                 self.flat.div_(ws)
 
 
@@ -62,7 +86,7 @@ class ShardedSpectralTrainer:
         self.group = group
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             for p in self.net.parameters():
-                dist.broadcast(p.data, src=0, group=group)
+                broadcast(p.data, 0, group)
         self.grads = FlatGradients(list(self.net.parameters()))
         self.optimizer = torch.optim.Adam(self.net.parameters(), lr=lr)
         self.criterion = SpectralNetLoss()
@@ -98,5 +122,5 @@ class ShardedSpectralTrainer:
             Y = self.net(x.to(self.device), should_update_orth_weights=False)
             total += self.criterion(b, Y, is_normalized=True)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            dist.all_reduce(total, group=self.group)
+            all_reduce_sum(total, self.group)
         return total
