@@ -111,7 +111,7 @@ def main():
     t0 = time.perf_counter()
     graph, bounds = synth.planted_cluster_graph(n, n_edges, n_clusters, dev, seed=0)
     torch.cuda.synchronize()
-    nodes_of = synth.cluster_batches(bounds, shape["bsize"], seed=0)
+    nodes_of, cluster_ids = synth.cluster_batches(bounds, shape["bsize"], seed=0, return_clusters=True)
     t_graph = time.perf_counter() - t0
     log(f"[bench] graph: {n} nodes, {int(graph.indices.numel())} stored entries, {len(nodes_of)} batches, {t_graph:.1f}s")
 
@@ -121,7 +121,8 @@ def main():
     for b in mine:
         pt = nodes_of[b]
         coords, values, shp, _ = graph.subblock(pt, mode=(0 if lam == -1 else 2), binarize=False, diag_lambda=lam)
-        cb = ClusterBatch.from_device_coo(shp[0], coords, values)
+        csz = np.diff(bounds.cpu().numpy())[cluster_ids[b]]
+        cb = ClusterBatch.from_device_coo(shp[0], coords, values, cluster_sizes=csz)
         trainer.add_batch(synth.block_features(pt, bounds, din, 47), cb)
     torch.cuda.synchronize()
     t_prep = time.perf_counter() - t0

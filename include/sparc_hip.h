@@ -85,17 +85,41 @@ int sparc_affinity_prep(int64_t m, int64_t nnz, const int64_t* rowptr, const int
  * rank-3 correction, the diagonal removal, the row scaling, the per-row dot products of the
  * loss and the gradient in its epilogue.  Y is [m][ldy] with k <= ldy; gradY is [m][ldy].
  * loss is one device double. */
-size_t sparc_lap_workspace_bytes(int64_t m, int k);
+size_t sparc_lap_workspace_bytes(int64_t m, int k, int ntiles);
 int sparc_lap_fwd(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* colidx,
                   const float* val, const float* valT, const float* rowc, const double* coupling,
                   int k, int64_t ldy, const float* Y, double* loss, float* gradY,
+                  const int32_t* tiles, int ntiles, int tile_rows,
                   void* ws, size_t ws_bytes, sparc_stream_t stream);
 
-/* Plain product Z = A X (+ X0 if X0 != NULL) on the same kernel, X, X0, Z [m][width] with
- * width in {16, 32, 64, 128}.  Exposed for roofline measurements on whole graphs. */
+/* Cluster tiling (optional, tiles == NULL selects the plain row kernel).  `tiles` is one device
+ * buffer of int32 in two parts:
+ *   ntiles descriptors  {q_begin, q_end, win_begin, win_end, slab, n_long, 0, 0}
+ *   m row records       {row, lo, hi, n_out, col0, col1, val0, valT0, val1, valT1, 0, 0}
+ * A workgroup with slab >= 0 stages rows [win_begin, win_end) of the dense operand (one column
+ * slab wide) in LDS and produces the rows of records [q_begin, q_end), all inside its window.
+ * [lo, hi) are the positions in colidx of the row's entries whose column lies in the window;
+ * the row's other entries (n_out of them, at most SPARC_TILE_MAX_OUTSIDE) are repeated in the
+ * record itself: column and the float bits of val / valT; they are gathered from global memory.
+ * Records of one workgroup are sorted by hi - lo, longest first: the first n_long of them (rows
+ * with more than SPARC_TILE_LONG_ROW in-window entries) get a whole wavefront each, the others
+ * share a wavefront four at a time and the first of the four bounds its trip count: it MUST be
+ * the longest of the four.  Rows
+ * with more outside entries belong to workgroups with slab = -1, which gather the rows of their
+ * records whole from global memory.  Every (row, slab) pair must be produced exactly once.  A
+ * slab is 32 columns of each half for the training pass (slab < kp/32, kp = k rounded up to
+ * 16/32/64; used when kp >= 32) or all 64 columns for the forward-only pass (slab = 0; used when
+ * kp == 64).  tile_rows = the largest window, at most SPARC_TILE_MAX_ROWS; nnz < 2^31. */
+#define SPARC_TILE_MAX_ROWS 512
+#define SPARC_TILE_MAX_OUTSIDE 2
+#define SPARC_TILE_LONG_ROW 64
+
+/* Plain product Z = A X (+ X0 if X0 != NULL) on the same kernels, X, X0, Z [m][width] with
+ * width in {16, 32, 64, 128} (tiles: width 64 only, slab 0).  Exposed for roofline
+ * measurements on whole graphs. */
 int sparc_spmm(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* colidx,
                const float* val, int width, const float* X, const float* X0, float* Z,
-               sparc_stream_t stream);
+               const int32_t* tiles, int ntiles, int tile_rows, sparc_stream_t stream);
 
 /* Measurement aid (no counterpart in the reference): between begin and end, every launch of the
  * row-gather kernel with the given epilogue (1 = the two inner passes of sparc_lap_fwd and

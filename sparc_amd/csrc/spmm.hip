@@ -1,23 +1,156 @@
-// CSR row-gather product for cluster batches and the fused Laplacian/loss epilogue.
+// CSR row-gather products for cluster batches and the fused Laplacian / loss epilogue.
 //
-// One wavefront owns one row of the batch.  The row's column indices and values
-// are streamed coalesced (one element per lane, 64 at a time) and handed to the
-// consuming lanes with cross-lane reads; the dense operand X is gathered as
-// whole rows, 16 bytes per lane, so that 64/LR rows of X arrive per wave
-// instruction (LR = lanes that cover one row of X).  Partial sums of the 64/LR
-// lane groups are combined with a butterfly at the end of the row.
+// Two kernels share one epilogue:
 //
-// In "dual" mode X is [Yn | Yn/rho]: the left half is multiplied by A (val), the
-// right half by A^T (valT, same pattern), so the forward product W Yn and the
-// backward product W^T Yn share one pass over the index stream.
+//  spmm_rows   one wavefront per row.  The row's column indices and values are streamed
+//              coalesced (one element per lane, 64 at a time) and handed to the consuming
+//              lanes with cross-lane reads; rows of the dense operand X are gathered from
+//              global memory (L2), 16 bytes per lane, 64/LR rows per wave instruction.
+//
+//  spmm_tiled  one workgroup per (window of rows, column slab, part of the window's rows).
+//              The window's rows of X (one slab wide) are staged in LDS once; every stored
+//              entry whose column falls in the window (the cluster-diagonal block, i.e.
+//              nearly all of a cluster batch) is gathered from LDS, the rest from global
+//              memory.  The row's entries are spread over the four 16-lane DPP rows of the
+//              wave and broadcast inside each with v_mov_dpp row_newbcast, so the LDS pipe
+//              carries nothing but the 16-byte gathers.
+//
+// In "dual" mode X is [Yn | Yn/rho]: the left half is multiplied by A (val), the right half
+// by A^T (valT, same pattern), so W Yn and W^T Yn share one pass over the index stream.
+#include <cstdlib>
 #include <vector>
 
 #include "spmm.h"
 
 namespace {
 
-constexpr int ROWS_PER_BLOCK = 4;  // one row per wave
+constexpr int ROWS_PER_BLOCK = 4;  // spmm_rows: one row per wave
+constexpr int TILED_THREADS = 1024;
+constexpr int TILED_WAVES = TILED_THREADS / 64;
 
+// ------------------------------------------------------------------ shared epilogue
+// A lane owns 4 consecutive columns of one row: `gcol` is their offset inside the row of the
+// global operand (row stride wtot floats), `cl` their index inside the half (0..kp-1), `right`
+// tells the A^T half from the A half, `half` is the lane distance between the two halves.
+struct RowPre {  // what the epilogue reads of its own row, requested before the gathers
+    float4 x0, rc0, rc1;
+};
+
+template <int EPI>
+__device__ __forceinline__ RowPre row_preload(const SpmmArgs& a, const int64_t row, const int wtot, const int gcol) {
+    RowPre r;
+    r.x0 = r.rc0 = r.rc1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (EPI == EPI_ADD_X0 || EPI == EPI_LAP_SINGLE || EPI == EPI_LAP_DUAL)
+        r.x0 = *reinterpret_cast<const float4*>(a.X0 + row * wtot + gcol);
+    if (EPI == EPI_LAP_SINGLE || EPI == EPI_LAP_DUAL) {
+        r.rc0 = *reinterpret_cast<const float4*>(a.rowc + row * SPARC_ROWC);
+        r.rc1 = *reinterpret_cast<const float4*>(a.rowc + row * SPARC_ROWC + 4);
+    }
+    return r;
+}
+
+// ROWS = rows per wave: 1 (the wave's owner lanes hold one row) or 4 (one row per 16-lane group).
+template <int ROWS>
+__device__ __forceinline__ double rows_sum(double v) {
+    if (ROWS == 1) return wave_sum(v);
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+template <bool DUAL, int EPI, int ROWS = 1>
+__device__ __forceinline__ void row_epilogue(const SpmmArgs& a, const int64_t row, const int lane, const bool owner,
+                                             const int half, const int kp, const int wtot, const int gcol,
+                                             const int cl, const bool right, const RowPre& pre, float4 acc,
+                                             double& wloss) {
+    const int64_t ro = row * wtot + gcol;
+    if (EPI == EPI_STORE) {
+        if (owner) *reinterpret_cast<float4*>(a.out + ro) = acc;
+    } else if (EPI == EPI_ADD_X0) {
+        if (owner) {
+            const float4 x0 = pre.x0;
+            *reinterpret_cast<float4*>(a.out + ro) = make_float4(acc.x + x0.x, acc.y + x0.y, acc.z + x0.z, acc.w + x0.w);
+        }
+    } else if (EPI == EPI_ADD_IDENT) {
+        if (owner) {
+            const int64_t cb = a.col0 + gcol;
+            acc.x += (cb + 0 == row) ? 1.f : 0.f;
+            acc.y += (cb + 1 == row) ? 1.f : 0.f;
+            acc.z += (cb + 2 == row) ? 1.f : 0.f;
+            acc.w += (cb + 3 == row) ? 1.f : 0.f;
+            *reinterpret_cast<float4*>(a.out + ro) = acc;
+        }
+    } else if (EPI == EPI_PREP_ACC) {
+        // acc holds S[row, col0 + gcol .. +3]; gather the row statistics of S
+        double ss = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        if (owner) {
+            const float vals[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t cj = a.col0 + gcol + q;
+                if (cj < a.m && cj != row) {
+                    const double sv = static_cast<double>(vals[q]);
+                    ss += sv * sv;
+                    s0 += sv;
+                    s1 += sv * a.cvec[cj];
+                    s2 += sv * a.c2vec[cj];
+                }
+            }
+        }
+        ss = rows_sum<ROWS>(ss); s0 = rows_sum<ROWS>(s0); s1 = rows_sum<ROWS>(s1); s2 = rows_sum<ROWS>(s2);
+        if (owner && (ROWS == 1 ? lane == 0 : (lane & 15) == 0)) {
+            double* r = a.racc + row * 8;
+            r[0] += ss; r[1] += s0; r[2] += s1; r[3] += s2;
+        }
+    } else {  // EPI_LAP_SINGLE / EPI_LAP_DUAL
+        // rowc: {+-1/rho, S_ii, d+cw, 1/sqrt(d)}, {r, r2, c, c2}; a negative 1/rho marks a row without
+        // off-diagonal entries, whose chain result is exactly S_ii x and is dropped instead of cancelled
+        const float4 rc0 = pre.rc0, rc1 = pre.rc1, x0 = pre.x0;
+        const bool isolated = rc0.x < 0.f;
+        const float irho = fabsf(rc0.x);
+        const float* Mb = a.M12 + (right ? 3 * kp : 0) + cl;
+        const float* Cf = a.M12 + 6 * kp;  // the 3x3 coupling, row-major
+        // diagonal of U C V^T for this row
+        const float ldiag = (Cf[0] + Cf[1] * rc1.z + Cf[2] * rc1.w) + rc1.x * (Cf[3] + Cf[4] * rc1.z + Cf[5] * rc1.w) +
+                            rc1.y * (Cf[6] + Cf[7] * rc1.z + Cf[8] * rc1.w);
+        const float u1 = right ? rc1.z : rc1.x, u2 = right ? rc1.w : rc1.y;
+        const float4 ma = *reinterpret_cast<const float4*>(Mb);
+        const float4 mb = *reinterpret_cast<const float4*>(Mb + kp);
+        const float4 mc = *reinterpret_cast<const float4*>(Mb + 2 * kp);
+        float4 t;
+        t.x = (isolated ? 0.f : acc.x - rc0.y * x0.x) + ((ma.x + u1 * mb.x + u2 * mc.x) - ldiag * x0.x);
+        t.y = (isolated ? 0.f : acc.y - rc0.y * x0.y) + ((ma.y + u1 * mb.y + u2 * mc.y) - ldiag * x0.y);
+        t.z = (isolated ? 0.f : acc.z - rc0.y * x0.z) + ((ma.z + u1 * mb.z + u2 * mc.z) - ldiag * x0.z);
+        t.w = (isolated ? 0.f : acc.w - rc0.y * x0.w) + ((ma.w + u1 * mb.w + u2 * mc.w) - ldiag * x0.w);
+        float4 wt = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (DUAL) {  // W^T Yn sits `half` lanes to the right of W Yn
+            wt.x = __shfl(t.x, lane + half);
+            wt.y = __shfl(t.y, lane + half);
+            wt.z = __shfl(t.z, lane + half);
+            wt.w = __shfl(t.w, lane + half);
+        }
+        double dot = 0.0;
+        if (owner && !right) {
+            const float4 wy = make_float4(irho * t.x, irho * t.y, irho * t.z, irho * t.w);
+            const float hd = 0.5f * rc0.z;
+            const float ly0 = hd * x0.x - wy.x, ly1 = hd * x0.y - wy.y, ly2 = hd * x0.z - wy.z, ly3 = hd * x0.w - wy.w;
+            dot = static_cast<double>(x0.x) * ly0 + static_cast<double>(x0.y) * ly1 +
+                  static_cast<double>(x0.z) * ly2 + static_cast<double>(x0.w) * ly3;
+            if (DUAL) {
+                const float sc = a.inv_m * rc0.w;
+                const float gy[4] = {(rc0.z * x0.x - wy.x - wt.x) * sc, (rc0.z * x0.y - wy.y - wt.y) * sc,
+                                     (rc0.z * x0.z - wy.z - wt.z) * sc, (rc0.z * x0.w - wy.w - wt.w) * sc};
+                float* gp = a.gradY + row * a.ldy + cl;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (cl + q < a.k) gp[q] = gy[q];
+            }
+        }
+        wloss += wave_sum(dot);
+    }
+}
+
+// ------------------------------------------------------------------ spmm_rows
 // U gathers in flight: the U rows of X are requested before the first is consumed.
 template <int LR, bool DUAL, int U>
 __device__ __forceinline__ void gather_rows(float4& acc, const int c, const float v, const float vt, const int it,
@@ -46,145 +179,59 @@ __device__ __forceinline__ void gather_rows(float4& acc, const int c, const floa
     }
 }
 
+// One row, gathered from global memory by the whole wave.
 template <int LR, bool DUAL, int EPI>
-__global__ __launch_bounds__(256) void spmm_rows(const SpmmArgs a) {
+__device__ __forceinline__ void wave_row_global(const SpmmArgs& a, const int64_t row, const int lane, double& wloss) {
     constexpr int W = LR * 4;       // floats per row of X
     constexpr int G = 64 / LR;      // rows of X gathered per wave instruction
     constexpr int HALF = LR / 2;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane / LR, lr = lane % LR;
+    const int64_t p0 = a.rowptr[row], p1 = a.rowptr[row + 1];
+    const RowPre pre = row_preload<EPI>(a, row, W, lr * 4);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t p = p0; p < p1; p += 64) {
+        const int cnt = static_cast<int>(min(static_cast<int64_t>(64), p1 - p));
+        int c = 0;
+        float v = 0.f, vt = 0.f;
+        if (lane < cnt) {
+            c = a.col[p + lane];
+            v = a.val[p + lane];
+            if (DUAL) vt = a.valT[p + lane];
+        }
+        // idle lanes point at a row that is read anyway and carry a zero weight
+        const int c_first = __shfl(c, 0);
+        if (lane >= cnt) c = c_first;
+        const int iters = (cnt + G - 1) / G;  // wave-uniform; (iters - 1) * G + g <= 63
+        int it = 0;
+        if (G <= 8)
+            for (; it + 8 <= iters; it += 8) gather_rows<LR, DUAL, 8>(acc, c, v, vt, it, g, lr, a.Xg);
+        if (it + 4 <= iters) { gather_rows<LR, DUAL, 4>(acc, c, v, vt, it, g, lr, a.Xg); it += 4; }
+        if (it + 2 <= iters) { gather_rows<LR, DUAL, 2>(acc, c, v, vt, it, g, lr, a.Xg); it += 2; }
+        if (it < iters) gather_rows<LR, DUAL, 1>(acc, c, v, vt, it, g, lr, a.Xg);
+    }
+#pragma unroll
+    for (int off = LR; off < 64; off <<= 1) {
+        acc.x += __shfl_xor(acc.x, off);
+        acc.y += __shfl_xor(acc.y, off);
+        acc.z += __shfl_xor(acc.z, off);
+        acc.w += __shfl_xor(acc.w, off);
+    }
+    const bool right = DUAL && lr >= HALF;
+    const int kp = DUAL ? W / 2 : W;
+    const int cl = (DUAL ? (lr % HALF) : lr) * 4;
+    row_epilogue<DUAL, EPI>(a, row, lane, g == 0, HALF, kp, W, lr * 4, cl, right, pre, acc, wloss);
+}
+
+template <int LR, bool DUAL, int EPI>
+__global__ __launch_bounds__(256) void spmm_rows(const SpmmArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
     double wloss = 0.0;
-
     for (int rr = wave; rr < ROWS_PER_BLOCK; rr += 4) {
         const int64_t row = blk * ROWS_PER_BLOCK + rr;
         if (row >= a.m) break;
-        const int64_t p0 = a.rowptr[row], p1 = a.rowptr[row + 1];
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int64_t p = p0; p < p1; p += 64) {
-            const int cnt = static_cast<int>(min(static_cast<int64_t>(64), p1 - p));
-            int c = 0;
-            float v = 0.f, vt = 0.f;
-            if (lane < cnt) {
-                c = a.col[p + lane];
-                v = a.val[p + lane];
-                if (DUAL) vt = a.valT[p + lane];
-            }
-            // idle lanes point at a row that is read anyway and carry a zero weight
-            const int c_first = __shfl(c, 0);
-            if (lane >= cnt) c = c_first;
-            const int iters = (cnt + G - 1) / G;  // wave-uniform; (iters - 1) * G + g <= 63
-            int it = 0;
-            if (G <= 8)
-                for (; it + 8 <= iters; it += 8) gather_rows<LR, DUAL, 8>(acc, c, v, vt, it, g, lr, a.Xg);
-            if (it + 4 <= iters) { gather_rows<LR, DUAL, 4>(acc, c, v, vt, it, g, lr, a.Xg); it += 4; }
-            if (it + 2 <= iters) { gather_rows<LR, DUAL, 2>(acc, c, v, vt, it, g, lr, a.Xg); it += 2; }
-            if (it < iters) gather_rows<LR, DUAL, 1>(acc, c, v, vt, it, g, lr, a.Xg);
-        }
-#pragma unroll
-        for (int off = LR; off < 64; off <<= 1) {
-            acc.x += __shfl_xor(acc.x, off);
-            acc.y += __shfl_xor(acc.y, off);
-            acc.z += __shfl_xor(acc.z, off);
-            acc.w += __shfl_xor(acc.w, off);
-        }
-        const int64_t ro = row * W + lr * 4;
-
-        if (EPI == EPI_STORE) {
-            if (g == 0) *reinterpret_cast<float4*>(a.out + ro) = acc;
-        } else if (EPI == EPI_ADD_X0) {
-            if (g == 0) {
-                const float4 x0 = *reinterpret_cast<const float4*>(a.X0 + ro);
-                *reinterpret_cast<float4*>(a.out + ro) = make_float4(acc.x + x0.x, acc.y + x0.y, acc.z + x0.z, acc.w + x0.w);
-            }
-        } else if (EPI == EPI_ADD_IDENT) {
-            if (g == 0) {
-                const int64_t cb = a.col0 + lr * 4;
-                acc.x += (cb + 0 == row) ? 1.f : 0.f;
-                acc.y += (cb + 1 == row) ? 1.f : 0.f;
-                acc.z += (cb + 2 == row) ? 1.f : 0.f;
-                acc.w += (cb + 3 == row) ? 1.f : 0.f;
-                *reinterpret_cast<float4*>(a.out + ro) = acc;
-            }
-        } else if (EPI == EPI_PREP_ACC) {
-            // acc holds S[row, col0 + 4 lr .. +3]; gather the row statistics of S
-            double ss = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0, sd = 0.0;
-            if (g == 0) {
-                const float vals[4] = {acc.x, acc.y, acc.z, acc.w};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int64_t cj = a.col0 + lr * 4 + q;
-                    if (cj < a.m) {
-                        const double sv = static_cast<double>(vals[q]);
-                        if (cj == row) {
-                            sd = sv;
-                        } else {
-                            ss += sv * sv;
-                            s0 += sv;
-                            s1 += sv * a.cvec[cj];
-                            s2 += sv * a.c2vec[cj];
-                        }
-                    }
-                }
-            }
-            ss = wave_sum(ss); s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); sd = wave_sum(sd);
-            if (lane == 0) {
-                double* r = a.racc + row * 8;
-                r[0] += ss; r[1] += s0; r[2] += s1; r[3] += s2; r[4] += sd;
-            }
-        } else {  // EPI_LAP_SINGLE / EPI_LAP_DUAL
-            // rowc: {+-1/rho, S_ii, d+cw, 1/sqrt(d)}, {r, r2, c, c2}; a negative 1/rho marks a row without
-            // off-diagonal entries, whose chain result is exactly S_ii x and is dropped instead of cancelled
-            const float4 rc0 = *reinterpret_cast<const float4*>(a.rowc + row * SPARC_ROWC);
-            const float4 rc1 = *reinterpret_cast<const float4*>(a.rowc + row * SPARC_ROWC + 4);
-            const float4 x0 = *reinterpret_cast<const float4*>(a.X0 + ro);
-            const bool isolated = rc0.x < 0.f;
-            const float irho = fabsf(rc0.x);
-            const bool right = DUAL && lr >= HALF;
-            const int KP = DUAL ? W / 2 : W;
-            const int cl = (DUAL ? (lr % HALF) : lr) * 4;
-            const float* Mb = a.M12 + (right ? 3 * KP : 0) + cl;
-            const float* Cf = a.M12 + 6 * KP;  // the 3x3 coupling, row-major
-            // diagonal of U C V^T for this row
-            const float ldiag = (Cf[0] + Cf[1] * rc1.z + Cf[2] * rc1.w) + rc1.x * (Cf[3] + Cf[4] * rc1.z + Cf[5] * rc1.w) +
-                                rc1.y * (Cf[6] + Cf[7] * rc1.z + Cf[8] * rc1.w);
-            const float u1 = right ? rc1.z : rc1.x, u2 = right ? rc1.w : rc1.y;
-            const float4 ma = *reinterpret_cast<const float4*>(Mb);
-            const float4 mb = *reinterpret_cast<const float4*>(Mb + KP);
-            const float4 mc = *reinterpret_cast<const float4*>(Mb + 2 * KP);
-            float4 t;
-            t.x = (isolated ? 0.f : acc.x - rc0.y * x0.x) + ((ma.x + u1 * mb.x + u2 * mc.x) - ldiag * x0.x);
-            t.y = (isolated ? 0.f : acc.y - rc0.y * x0.y) + ((ma.y + u1 * mb.y + u2 * mc.y) - ldiag * x0.y);
-            t.z = (isolated ? 0.f : acc.z - rc0.y * x0.z) + ((ma.z + u1 * mb.z + u2 * mc.z) - ldiag * x0.z);
-            t.w = (isolated ? 0.f : acc.w - rc0.y * x0.w) + ((ma.w + u1 * mb.w + u2 * mc.w) - ldiag * x0.w);
-            float4 wt = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (DUAL) {  // W^T Yn sits HALF lanes to the right of W Yn
-                wt.x = __shfl(t.x, lane + HALF);
-                wt.y = __shfl(t.y, lane + HALF);
-                wt.z = __shfl(t.z, lane + HALF);
-                wt.w = __shfl(t.w, lane + HALF);
-            }
-            double dot = 0.0;
-            if (g == 0 && !right) {
-                const float4 wy = make_float4(irho * t.x, irho * t.y, irho * t.z, irho * t.w);
-                const float hd = 0.5f * rc0.z;
-                const float ly0 = hd * x0.x - wy.x, ly1 = hd * x0.y - wy.y, ly2 = hd * x0.z - wy.z, ly3 = hd * x0.w - wy.w;
-                dot = static_cast<double>(x0.x) * ly0 + static_cast<double>(x0.y) * ly1 +
-                      static_cast<double>(x0.z) * ly2 + static_cast<double>(x0.w) * ly3;
-                if (DUAL) {
-                    const float sc = a.inv_m * rc0.w;
-                    const float gy[4] = {(rc0.z * x0.x - wy.x - wt.x) * sc, (rc0.z * x0.y - wy.y - wt.y) * sc,
-                                         (rc0.z * x0.z - wy.z - wt.z) * sc, (rc0.z * x0.w - wy.w - wt.w) * sc};
-                    float* gp = a.gradY + row * a.ldy + cl;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (cl + q < a.k) gp[q] = gy[q];
-                }
-            }
-            wloss += wave_sum(dot);
-        }
+        wave_row_global<LR, DUAL, EPI>(a, row, lane, wloss);
     }
-
     if (EPI == EPI_LAP_SINGLE || EPI == EPI_LAP_DUAL) {
         __shared__ double wl[4];
         if (lane == 0) wl[wave] = wloss;
@@ -193,6 +240,231 @@ __global__ __launch_bounds__(256) void spmm_rows(const SpmmArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ spmm_tiled
+// One workgroup = (window of rows, column slab, part of the window's rows).  A wave works on FOUR
+// rows at a time, one per 16-lane DPP row: lane (g, lr) owns 4 columns (16 bytes) of the slab of
+// row g.  The 16 lanes of a row load 16 consecutive stored entries; step u broadcasts entry u
+// inside each DPP row (v_mov_dpp row_newbcast) and gathers the operand row from the LDS window
+// with one ds_read_b128.  Rows arrive sorted by length (rowinfo), so the four rows of a wave are
+// equally long and row 0 of the wave bounds the trip count.  Rows with entries outside their
+// window (rare in a cluster batch) are not tiled at all: workgroups whose descriptor carries
+// slab < 0 gather them whole from global memory, so the hot loop has no second path.
+template <int N>
+__device__ __forceinline__ int row_bcast(const int x) {  // lane N of every 16-lane DPP row, to the whole row
+    return __builtin_amdgcn_mov_dpp(x, 0x150 + N, 0xf, 0xf, false);
+}
+template <int N>
+__device__ __forceinline__ float row_bcastf(const float x) {
+    return __int_as_float(row_bcast<N>(__float_as_int(x)));
+}
+
+struct Chunk {  // 16 stored entries of one row, one per lane of the DPP row
+    int addr;   // byte offset of the operand row inside the LDS window
+    float v, vt;
+};
+
+template <bool DUAL>
+__device__ __forceinline__ Chunk load_chunk(const SpmmArgs& a, const int lo, const int hi, const int base, const int lr,
+                                            const int w0, const int own_addr) {
+    Chunk ck;
+    ck.addr = own_addr;  // idle lanes: a row of the window, zero weight
+    ck.v = 0.f;
+    ck.vt = 0.f;
+    const int p = lo + base + lr;  // lr: position of the lane's entry inside the chunk
+    if (p < hi) {
+        ck.addr = (a.col[p] - w0) << 8;
+        ck.v = a.val[p];
+        if (DUAL) ck.vt = a.valT[p];
+    }
+    return ck;
+}
+
+template <bool DUAL, int U>
+__device__ __forceinline__ void tile_step(float4& acc, const Chunk& ck, const bool right, const int lr16,
+                                          const char* __restrict__ tile_bytes) {
+    const int addr = row_bcast<U>(ck.addr) + lr16;
+    float w = row_bcastf<U>(ck.v);
+    if (DUAL) {
+        const float wt = row_bcastf<U>(ck.vt);
+        w = right ? wt : w;
+    }
+    const float4 x = *reinterpret_cast<const float4*>(tile_bytes + addr);
+    acc.x = fmaf(w, x.x, acc.x);
+    acc.y = fmaf(w, x.y, acc.y);
+    acc.z = fmaf(w, x.z, acc.z);
+    acc.w = fmaf(w, x.w, acc.w);
+}
+
+// `steps` (1..16, wave-uniform, in an SGPR) entries of the chunk
+template <bool DUAL>
+__device__ __forceinline__ void tile_chunk(float4& acc, const Chunk& ck, const int steps, const bool right,
+                                           const int lr16, const char* __restrict__ tile_bytes) {
+#define SPARC_STEP4(U)                                       \
+    if (steps > U) {                                         \
+        tile_step<DUAL, U>(acc, ck, right, lr16, tile_bytes);     \
+        tile_step<DUAL, U + 1>(acc, ck, right, lr16, tile_bytes); \
+        tile_step<DUAL, U + 2>(acc, ck, right, lr16, tile_bytes); \
+        tile_step<DUAL, U + 3>(acc, ck, right, lr16, tile_bytes); \
+    }
+    SPARC_STEP4(0) SPARC_STEP4(4) SPARC_STEP4(8) SPARC_STEP4(12)
+#undef SPARC_STEP4
+}
+
+template <bool DUAL, int EPI>
+__global__ __launch_bounds__(TILED_THREADS) void spmm_tiled(const SpmmArgs a) {
+    extern __shared__ float4 tile[];  // [window rows][16 lanes] float4
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, lr = lane & 15;
+    const int32_t* d = a.desc + static_cast<int64_t>(blockIdx.x) * 8;
+    const int q_begin = d[0], q_end = d[1], w0 = d[2], wn = d[3] - d[2], slab = d[4];
+    const int kp = a.kp, wtot = a.wtot;
+    if (slab < 0) {
+        // Rows with entries outside their window: this workgroup gathers them whole from global
+        // memory (records [q_begin, q_end) of the row list, one row per wave at a time).
+        double gl = 0.0;
+        const int g_end = (a.dbg & 8) ? q_begin : q_end;
+        for (int q = q_begin + wave; q < g_end; q += TILED_WAVES) {
+            const int64_t row = a.rowinfo[12 * static_cast<int64_t>(q)];
+            if (DUAL) {
+                if (kp == 64) wave_row_global<32, true, EPI>(a, row, lane, gl);
+                else wave_row_global<16, true, EPI>(a, row, lane, gl);
+            } else {
+                wave_row_global<16, false, EPI>(a, row, lane, gl);
+            }
+        }
+        if (EPI == EPI_LAP_SINGLE || EPI == EPI_LAP_DUAL) {
+            __shared__ double gw[TILED_WAVES];
+            if (lane == 0) gw[wave] = gl;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double t = 0.0;
+                for (int w = 0; w < TILED_WAVES; ++w) t += gw[w];
+                a.loss_part[blockIdx.x] = t;
+            }
+        }
+        return;
+    }
+    // columns of this lane: dual = 8 lanes (32 floats) of the A half + 8 lanes of the A^T half,
+    // single = 16 lanes (64 floats)
+    const bool right = DUAL && lr >= 8;
+    const int cl = DUAL ? slab * 32 + (lr & 7) * 4 : slab * 64 + lr * 4;
+    const int gcol = (right ? kp : 0) + cl;
+
+    {   // stage the window with asynchronous global->LDS copies (no register round trip): one wave
+        // instruction moves 64 x 16 bytes to LDS base + lane * 16, the source address is per lane
+        const float* src = a.Xg + static_cast<int64_t>(w0) * wtot + gcol;
+        const int n16 = (a.dbg & 4) ? 0 : wn * 16;
+        for (int base = wave * 64; base < n16; base += TILED_THREADS) {
+            const int i = base + lane;
+            if (i < n16)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(src + static_cast<int64_t>(i >> 4) * wtot),
+                    (__attribute__((address_space(3))) void*)(tile + base), 16, 0, 0);
+        }
+    }
+    // the row records of this workgroup, in LDS: 3 x int4 per row =
+    // {row, lo, hi, n_outside}, {col0, col1, val0, valT0}, {val1, valT1, 0, 0}
+    __shared__ int4 info[SPARC_TILE_MAX_ROWS * 3];
+    const int nq = q_end - q_begin;
+    for (int i = threadIdx.x; i < nq * 3; i += TILED_THREADS)
+        info[i] = reinterpret_cast<const int4*>(a.rowinfo)[static_cast<int64_t>(q_begin) * 3 + i];
+    const char* tile_bytes = reinterpret_cast<const char*>(tile);
+    const int lr16 = lr * 16;
+    __syncthreads();  // the window and the records have landed (the barrier waits for the LDS copies)
+
+    // A wave owns slots wave, wave + 16, ... (4 rows each).  The entries and epilogue operands of a
+    // slot are requested two slots ahead: global-memory latency hides behind two slots of LDS work.
+    // Up to two entries of a row may lie outside the window; their columns and values travel in the
+    // row record, so their operand rows are requested from global memory with the same prefetch.
+    struct Slot {
+        int4 ri;
+        Chunk c0, c1;
+        RowPre pre;
+        float ow0, ow1;
+        float4 ox0, ox1;
+    };
+    // Slots: the first n_long records are long rows (more than SPARC_TILE_LONG_ROW in-window entries),
+    // each worked on by the whole wave (DPP row g takes entries g, g + 4, ...; the four partial sums
+    // are merged at the end); the other records are taken four at a time, one row per DPP row.
+    const int n_long = d[5];
+    const int nslots = (a.dbg & 1) ? 0 : n_long + (nq - n_long + 3) / 4;
+    auto fetch = [&](const int slot) {
+        Slot s;
+        const bool lng = slot < n_long;
+        const int qi = lng ? slot : n_long + (slot - n_long) * 4 + g;
+        s.ri = make_int4(-1, 0, 0, 0);
+        s.ow0 = s.ow1 = 0.f;
+        s.ox0 = s.ox1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (slot < nslots && qi < nq) {
+            s.ri = info[qi * 3];
+            if (s.ri.w > 0 && (!lng || g == 0)) {
+                const int4 o0 = info[qi * 3 + 1];
+                s.ow0 = __int_as_float(right ? o0.w : o0.z);
+                s.ox0 = *reinterpret_cast<const float4*>(a.Xg + static_cast<int64_t>(o0.x) * wtot + gcol);
+                if (s.ri.w > 1) {
+                    const int4 o1 = info[qi * 3 + 2];
+                    s.ow1 = __int_as_float(right ? o1.y : o1.x);
+                    s.ox1 = *reinterpret_cast<const float4*>(a.Xg + static_cast<int64_t>(o0.y) * wtot + gcol);
+                }
+            }
+        }
+        const int off = lng ? lr * 4 + g : lr;  // entry of this lane inside a chunk
+        s.c0 = load_chunk<DUAL>(a, s.ri.y, s.ri.z, 0, off, w0, 0);
+        s.c1 = load_chunk<DUAL>(a, s.ri.y, s.ri.z, lng ? 64 : 16, off, w0, 0);
+        s.pre = row_preload<EPI_STORE>(a, 0, 0, 0);
+        if (s.ri.x >= 0) s.pre = row_preload<EPI>(a, s.ri.x, wtot, gcol);
+        return s;
+    };
+    // slots are sorted by work, longest first, and dealt to the waves in serpentine order
+    auto slot_of = [&](const int round) { return round * TILED_WAVES + ((round & 1) ? TILED_WAVES - 1 - wave : wave); };
+    Slot cur = fetch(slot_of(0)), nxt = fetch(slot_of(1));
+
+    double wloss = 0.0;
+    for (int round = 0; round * TILED_WAVES < nslots; ++round) {  // wave-uniform
+        const Slot nn = fetch(slot_of(round + 2));
+        const bool lng = slot_of(round) < n_long;  // wave-uniform
+        const int4 ri = cur.ri;
+        // rows are sorted by length: DPP row 0 holds the longest of the four
+        const int nmax = __builtin_amdgcn_readfirstlane(ri.z - ri.y);
+        const int steps = (a.dbg & 2) ? 0 : (lng ? (nmax + 3) >> 2 : nmax);
+        const int cstride = lng ? 64 : 16;  // entries per chunk
+        const int off = lng ? lr * 4 + g : lr;
+        float4 acc;  // starts from the (at most two) entries outside the window
+        acc.x = fmaf(cur.ow1, cur.ox1.x, cur.ow0 * cur.ox0.x);
+        acc.y = fmaf(cur.ow1, cur.ox1.y, cur.ow0 * cur.ox0.y);
+        acc.z = fmaf(cur.ow1, cur.ox1.z, cur.ow0 * cur.ox0.z);
+        acc.w = fmaf(cur.ow1, cur.ox1.w, cur.ow0 * cur.ox0.w);
+        if (steps > 0) tile_chunk<DUAL>(acc, cur.c0, min(steps, 16), right, lr16, tile_bytes);
+        if (steps > 16) tile_chunk<DUAL>(acc, cur.c1, min(steps - 16, 16), right, lr16, tile_bytes);
+        for (int c = 2; c * 16 < steps; ++c) {
+            const Chunk ck = load_chunk<DUAL>(a, ri.y, ri.z, c * cstride, off, w0, 0);
+            tile_chunk<DUAL>(acc, ck, min(steps - c * 16, 16), right, lr16, tile_bytes);
+        }
+        if (lng) {  // merge the four DPP rows
+            acc.x += __shfl_xor(acc.x, 16); acc.y += __shfl_xor(acc.y, 16);
+            acc.z += __shfl_xor(acc.z, 16); acc.w += __shfl_xor(acc.w, 16);
+            acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32);
+            acc.z += __shfl_xor(acc.z, 32); acc.w += __shfl_xor(acc.w, 32);
+        }
+        row_epilogue<DUAL, EPI, 4>(a, ri.x, lane, ri.x >= 0 && (!lng || g == 0), 8, kp, wtot, gcol, cl, right, cur.pre,
+                                   acc, wloss);
+        cur = nxt;
+        nxt = nn;
+    }
+
+    if (EPI == EPI_LAP_SINGLE || EPI == EPI_LAP_DUAL) {
+        __shared__ double wl[TILED_WAVES];
+        if (lane == 0) wl[wave] = wloss;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int w = 0; w < TILED_WAVES; ++w) t += wl[w];
+            a.loss_part[blockIdx.x] = t;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ small kernels of the Laplacian pass
 // X = [Y/sqrt(d) | Y/(sqrt(d) rho)] (zero padded to KP columns per half) and the block
 // partial column sums V^T Yn (3 rows) and U^T X2 (3 rows).
 template <int KP, bool DUAL>
@@ -281,6 +553,7 @@ __global__ __launch_bounds__(256) void loss_finish(int64_t n, const double* __re
     if (threadIdx.x == 0) *loss = sm[0] * scale;
 }
 
+// ------------------------------------------------------------------ launch helpers
 // Optional timing of one kernel class with HIP events recorded on the launch stream.
 struct Profiler {
     int epi = -1;                 // which epilogue class is timed
@@ -288,17 +561,51 @@ struct Profiler {
     size_t used = 0;
 } g_prof;
 
+struct Timed {
+    bool on;
+    hipStream_t s;
+    Timed(int epi, hipStream_t stream) : on(g_prof.epi == epi && g_prof.used + 2 <= g_prof.ev.size()), s(stream) {
+        if (on) (void)hipEventRecord(g_prof.ev[g_prof.used], s);
+    }
+    ~Timed() {
+        if (on) {
+            (void)hipEventRecord(g_prof.ev[g_prof.used + 1], s);
+            g_prof.used += 2;
+        }
+    }
+};
+
 template <int LR, bool DUAL, int EPI>
 int launch_rows(const SpmmArgs& a, hipStream_t stream) {
     const int64_t nb = (a.m + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
     if (nb <= 0) return SPARC_OK;
     if (nb > 0x7fffffffLL) return SPARC_ERR_ARG;
-    const bool timed = g_prof.epi == EPI && g_prof.used + 2 <= g_prof.ev.size();
-    if (timed) (void)hipEventRecord(g_prof.ev[g_prof.used], stream);
-    hipLaunchKernelGGL((spmm_rows<LR, DUAL, EPI>), dim3(static_cast<unsigned>(nb)), dim3(256), 0, stream, a);
-    if (timed) {
-        (void)hipEventRecord(g_prof.ev[g_prof.used + 1], stream);
-        g_prof.used += 2;
+    {
+        Timed t(EPI, stream);
+        hipLaunchKernelGGL((spmm_rows<LR, DUAL, EPI>), dim3(static_cast<unsigned>(nb)), dim3(256), 0, stream, a);
+    }
+    SPARC_CHECK_LAUNCH();
+    return SPARC_OK;
+}
+
+template <bool DUAL, int EPI>
+int launch_tiled(const SpmmArgs& a, hipStream_t stream) {
+    const size_t lds = static_cast<size_t>(a.tile_rows) * 16 * sizeof(float4);
+    if (a.ndesc <= 0) return SPARC_OK;
+    if (lds > SPARC_TILE_LDS_BYTES) return SPARC_ERR_ARG;
+    static bool configured = false;  // per instantiation: allow the large dynamic LDS allocation
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_tiled<DUAL, EPI>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, SPARC_TILE_LDS_BYTES) != hipSuccess)
+            return SPARC_ERR_LAUNCH;
+        configured = true;
+    }
+    {
+        SpmmArgs b = a;
+        const char* dbg = getenv("SPARC_DBG");
+        b.dbg = dbg ? atoi(dbg) : 0;
+        Timed t(EPI, stream);
+        hipLaunchKernelGGL((spmm_tiled<DUAL, EPI>), dim3(static_cast<unsigned>(a.ndesc)), dim3(TILED_THREADS), lds, stream, b);
     }
     SPARC_CHECK_LAUNCH();
     return SPARC_OK;
@@ -306,6 +613,7 @@ int launch_rows(const SpmmArgs& a, hipStream_t stream) {
 
 template <int EPI>
 int launch_single(int width, const SpmmArgs& a, hipStream_t s) {
+    if (a.desc && width == 64) return launch_tiled<false, EPI>(a, s);
     switch (width) {
         case 16: return launch_rows<4, false, EPI>(a, s);
         case 32: return launch_rows<8, false, EPI>(a, s);
@@ -317,6 +625,7 @@ int launch_single(int width, const SpmmArgs& a, hipStream_t s) {
 
 template <int EPI>
 int launch_dual(int kp, const SpmmArgs& a, hipStream_t s) {
+    if (a.desc && (kp == 32 || kp == 64)) return launch_tiled<true, EPI>(a, s);
     switch (kp) {
         case 16: return launch_rows<8, true, EPI>(a, s);
         case 32: return launch_rows<16, true, EPI>(a, s);
@@ -335,8 +644,8 @@ int sparc_spmm_launch(int epi, int width, const SpmmArgs& a, hipStream_t stream)
     switch (epi) {
         case EPI_STORE: return launch_single<EPI_STORE>(width, a, stream);
         case EPI_ADD_X0: return launch_single<EPI_ADD_X0>(width, a, stream);
-        case EPI_ADD_IDENT: return width == 64 ? launch_rows<16, false, EPI_ADD_IDENT>(a, stream) : SPARC_ERR_ARG;
-        case EPI_PREP_ACC: return width == 64 ? launch_rows<16, false, EPI_PREP_ACC>(a, stream) : SPARC_ERR_ARG;
+        case EPI_ADD_IDENT: return width == 64 ? launch_single<EPI_ADD_IDENT>(64, a, stream) : SPARC_ERR_ARG;
+        case EPI_PREP_ACC: return width == 64 ? launch_single<EPI_PREP_ACC>(64, a, stream) : SPARC_ERR_ARG;
     }
     return SPARC_ERR_ARG;
 }
@@ -371,12 +680,35 @@ extern "C" int sparc_profile_end(double* total_ms, int64_t* launches) {
     return SPARC_OK;
 }
 
+namespace {
+// Checks the tiling arguments that can be checked on the host; fills the SpmmArgs fields.
+int set_tiles(SpmmArgs& a, const int32_t* tiles, int ntiles, int tile_rows, int kp, int wtot) {
+    a.kp = kp;
+    a.wtot = wtot;
+    a.desc = nullptr;
+    a.rowinfo = nullptr;
+    a.ndesc = 0;
+    a.tile_rows = 0;
+    if (!tiles) return SPARC_OK;
+    if (ntiles <= 0 || tile_rows <= 0 || tile_rows > SPARC_TILE_MAX_ROWS) return SPARC_ERR_ARG;
+    a.desc = tiles;
+    a.rowinfo = tiles + static_cast<int64_t>(ntiles) * 8;  // the row records follow the descriptors
+    a.ndesc = ntiles;
+    a.tile_rows = tile_rows;
+    return SPARC_OK;
+}
+}  // namespace
+
 extern "C" int sparc_spmm(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* colidx, const float* val,
-                          int width, const float* X, const float* X0, float* Z, sparc_stream_t stream) {
+                          int width, const float* X, const float* X0, float* Z, const int32_t* tiles, int ntiles,
+                          int tile_rows, sparc_stream_t stream) {
     if (m < 0 || nnz < 0 || !rowptr || (nnz > 0 && (!colidx || !val)) || !X || !Z) return SPARC_ERR_ARG;
     SpmmArgs a = {};
     a.m = m; a.rowptr = rowptr; a.col = colidx; a.val = val; a.valT = val;
     a.Xg = X; a.X0 = X0; a.out = Z;
+    if (tiles && width != 64) return SPARC_ERR_ARG;
+    const int rc = set_tiles(a, tiles, ntiles, tile_rows, width, width);
+    if (rc) return rc;
     return sparc_spmm_launch(X0 ? EPI_ADD_X0 : EPI_STORE, width, a, stream);
 }
 
@@ -387,7 +719,7 @@ struct LapPlan {
     int64_t nscale, rows_per_block, nloss;
     size_t bytes;
 };
-LapPlan lap_plan(int64_t m, int k) {
+LapPlan lap_plan(int64_t m, int k, int ntiles) {
     LapPlan p;
     p.kp = padded_k(k);
     p.W = 2 * p.kp;
@@ -402,6 +734,7 @@ LapPlan lap_plan(int64_t m, int k) {
     p.nscale = (m + rpb - 1) / rpb;
     if (p.nscale < 1) p.nscale = 1;
     p.nloss = sparc_rows_blocks(m);
+    if (ntiles > p.nloss) p.nloss = ntiles;
     p.bytes = 3 * sparc_align_up(static_cast<size_t>(m) * p.W * sizeof(float)) +
               sparc_align_up(static_cast<size_t>(SCALE_MAX_BLOCKS) * 6 * p.kp * sizeof(float)) +
               sparc_align_up((6 * SPARC_MAX_K + 16) * sizeof(float)) +
@@ -410,19 +743,19 @@ LapPlan lap_plan(int64_t m, int k) {
 }
 }  // namespace
 
-extern "C" size_t sparc_lap_workspace_bytes(int64_t m, int k) {
-    if (m < 0 || k < 1 || k > SPARC_MAX_K) return 0;
-    return lap_plan(m, k).bytes;
+extern "C" size_t sparc_lap_workspace_bytes(int64_t m, int k, int ntiles) {
+    if (m < 0 || k < 1 || k > SPARC_MAX_K || ntiles < 0) return 0;
+    return lap_plan(m, k, ntiles).bytes;
 }
 
 extern "C" int sparc_lap_fwd(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* colidx, const float* val,
                              const float* valT, const float* rowc, const double* coupling, int k, int64_t ldy,
-                             const float* Y, double* loss, float* gradY, void* ws, size_t ws_bytes,
-                             sparc_stream_t stream) {
+                             const float* Y, double* loss, float* gradY, const int32_t* tiles, int ntiles,
+                             int tile_rows, void* ws, size_t ws_bytes, sparc_stream_t stream) {
     if (m <= 0 || nnz < 0 || k < 1 || k > SPARC_MAX_K || ldy < k || !rowptr || !rowc || !coupling || !Y || !loss ||
-        (nnz > 0 && (!colidx || !val)))
+        (nnz > 0 && (!colidx || !val)) || ntiles < 0)
         return SPARC_ERR_ARG;
-    const LapPlan p = lap_plan(m, k);
+    const LapPlan p = lap_plan(m, k, tiles ? ntiles : 0);
     WsCarver c(ws, ws_bytes);
     const bool dual = gradY != nullptr;
     const int W = dual ? p.W : p.kp;
@@ -433,6 +766,16 @@ extern "C" int sparc_lap_fwd(int64_t m, int64_t nnz, const int64_t* rowptr, cons
     float* M12 = c.take<float>(6 * SPARC_MAX_K + 16);
     double* loss_part = c.take<double>(static_cast<size_t>(p.nloss));
     if (!ws || !c.ok()) return SPARC_ERR_WS;
+
+    SpmmArgs a = {};
+    a.m = m; a.rowptr = rowptr; a.col = colidx; a.val = val; a.valT = valT ? valT : val;
+    a.rowc = rowc; a.M12 = M12; a.loss_part = loss_part; a.gradY = gradY; a.ldy = ldy; a.k = k;
+    a.inv_m = static_cast<float>(1.0 / static_cast<double>(m));
+    // the tiled kernel covers 64-float single rows and 32- or 64-float halves of dual rows
+    const bool tiled = tiles && (dual ? p.kp >= 32 : p.kp == 64);
+    int rcode = set_tiles(a, tiled ? tiles : nullptr, ntiles, tile_rows, p.kp, W);
+    if (rcode) return rcode;
+    const int64_t nparts = tiled ? ntiles : sparc_rows_blocks(m);
 
     const dim3 gs(static_cast<unsigned>(p.nscale)), bs(256);
 #define SPARC_SCALE(KP)                                                                                              \
@@ -447,12 +790,7 @@ extern "C" int sparc_lap_fwd(int64_t m, int64_t nnz, const int64_t* rowptr, cons
                        colpart, coupling, M12);
     SPARC_CHECK_LAUNCH();
 
-    SpmmArgs a = {};
-    a.m = m; a.rowptr = rowptr; a.col = colidx; a.val = val; a.valT = valT ? valT : val;
-    a.rowc = rowc; a.M12 = M12; a.loss_part = loss_part; a.gradY = gradY; a.ldy = ldy; a.k = k;
-    a.inv_m = static_cast<float>(1.0 / static_cast<double>(m));
     a.X0 = X;
-    int rcode;
     // Horner: chain(X) = A (X + A (X + A X))
     a.Xg = X; a.out = P1;
     rcode = dual ? launch_dual<EPI_ADD_X0>(p.kp, a, stream) : launch_single<EPI_ADD_X0>(W, a, stream);
@@ -463,7 +801,7 @@ extern "C" int sparc_lap_fwd(int64_t m, int64_t nnz, const int64_t* rowptr, cons
     a.Xg = P2; a.out = nullptr;
     rcode = dual ? launch_dual<EPI_LAP_DUAL>(p.kp, a, stream) : launch_single<EPI_LAP_SINGLE>(W, a, stream);
     if (rcode) return rcode;
-    hipLaunchKernelGGL(loss_finish, dim3(1), dim3(256), 0, stream, p.nloss, loss_part, 1.0 / static_cast<double>(m), loss);
+    hipLaunchKernelGGL(loss_finish, dim3(1), dim3(256), 0, stream, nparts, loss_part, 1.0 / static_cast<double>(m), loss);
     SPARC_CHECK_LAUNCH();
     return SPARC_OK;
 }

@@ -16,6 +16,89 @@ from . import _lib
 from ._lib import check, lib
 
 EPS_BACKGROUND = 1e-6  # src/SpectralTrainer.py:288
+TILE_MAX_ROWS = 512     # SPARC_TILE_MAX_ROWS: rows of one LDS window (256 bytes each)
+TILE_LONG_ROW = 64       # SPARC_TILE_LONG_ROW: longer rows get a whole wavefront
+TILE_MAX_OUTSIDE = 2    # SPARC_TILE_MAX_OUTSIDE: entries of a row outside its window that ride in the row record
+TILE_TARGET_WGS = 256   # one workgroup per CU
+
+
+def plan_windows(m: int, cluster_sizes=None, max_rows: int = TILE_MAX_ROWS):
+    """Row windows [begin, end) for the LDS-tiled kernel: consecutive clusters are merged while
+    they fit one window, clusters larger than a window are split evenly; without cluster sizes
+    the rows are cut into equal windows."""
+    if cluster_sizes is None or int(np.sum(cluster_sizes)) != m:
+        cluster_sizes = [m]
+    bounds = [0]
+    for sz in cluster_sizes:
+        sz = int(sz)
+        if sz <= 0:
+            continue
+        if sz > max_rows:                         # split an oversized cluster evenly
+            parts = -(-sz // max_rows)
+            base, rem = divmod(sz, parts)
+            start = bounds[-1]
+            for i in range(parts):
+                start += base + (1 if i < rem else 0)
+                bounds.append(start)
+            continue
+        bounds.append(bounds[-1] + sz)
+    # merge neighbours greedily
+    wins, cur = [], 0
+    for i in range(1, len(bounds)):
+        if bounds[i] - cur > max_rows:
+            wins.append((cur, bounds[i - 1]))
+            cur = bounds[i - 1]
+    wins.append((cur, bounds[-1]))
+    return [(a, b) for a, b in wins if b > a]
+
+
+def plan_tiles(windows, lo: np.ndarray, hi: np.ndarray, n_out: np.ndarray, out_rec: np.ndarray, n_slabs: int,
+               target_wgs: int = TILE_TARGET_WGS):
+    """The tiling buffer of the LDS-tiled kernel (layout: include/sparc_hip.h): descriptors and row
+    records.  [lo, hi) are the positions of every row's in-window entries, n_out the number of
+    its other entries and out_rec int32[m][6] = {col0, col1, val0, valT0, val1, valT1} (float
+    bits) the first two of them.  Every window's rows are sorted by in-window length (longest
+    first) and dealt round-robin to J parts so that windows x slabs x J fills the chip with
+    equal work; rows with more than TILE_MAX_OUTSIDE outside entries go to slab = -1 workgroups,
+    which gather from global memory."""
+    nw = len(windows)
+    J = max(1, target_wgs // max(nw * n_slabs, 1))
+    desc, recs = [], []
+    q = 0
+    length = hi - lo
+    tiled_ok = n_out <= TILE_MAX_OUTSIDE
+
+    def records(rows):
+        z = np.zeros_like(rows)
+        head = np.stack([rows, lo[rows], hi[rows], np.minimum(n_out[rows], TILE_MAX_OUTSIDE)], axis=1)
+        return np.concatenate([head, out_rec[rows], np.stack([z, z], axis=1)], axis=1)
+
+    for (a, b) in windows:
+        rows = np.arange(a, b)
+        rows = rows[tiled_ok[a:b]]
+        if len(rows) == 0:
+            continue
+        order = rows[np.argsort(-length[rows], kind="stable")]
+        parts = max(1, min(J, (len(order) + 63) // 64))   # at least one row per 16-lane group of the workgroup
+        for j in range(parts):
+            mine = order[j::parts]
+            if len(mine) == 0:
+                continue
+            recs.append(records(mine))
+            n_long = int((length[mine] > TILE_LONG_ROW).sum())
+            for s_ in range(n_slabs):
+                desc.append((q, q + len(mine), a, b, s_, n_long, 0, 0))
+            q += len(mine)
+    loose = np.nonzero(~tiled_ok)[0]
+    if len(loose):
+        for part in np.array_split(loose, max(1, (len(loose) + 15) // 16)):
+            if len(part):
+                recs.append(records(part))
+                desc.append((q, q + len(part), 0, 0, -1, 0, 0, 0))
+                q += len(part)
+    desc = np.asarray(desc, dtype=np.int32).reshape(-1, 8)
+    recs = np.concatenate(recs, axis=0).astype(np.int32) if recs else np.zeros((0, 12), np.int32)
+    return desc, recs
 
 
 def _ptr(t):
@@ -58,12 +141,14 @@ class ClusterBatch:
     coupling (float64[16]).
     """
 
+    use_tiles = True  # class-wide switch between the LDS-tiled and the plain row kernel
+
     def __init__(self):
         self.m = 0
         self.nnz = 0
 
     @classmethod
-    def from_support(cls, support, device, eps: float = EPS_BACKGROUND) -> "ClusterBatch":
+    def from_support(cls, support, device, eps: float = EPS_BACKGROUND, cluster_sizes=None) -> "ClusterBatch":
         """support = (coords[nnz,2] (row, col), values[nnz], shape) as written by the
         reference's to_tuple (src/utils.py:41-47); values are cast to float32 as
         torch.FloatTensor(values) does (src/SpectralTrainer.py:277)."""
@@ -80,11 +165,15 @@ class ClusterBatch:
             values_d = values.to(device=device, dtype=torch.float64).contiguous()
         else:
             values_d = torch.from_numpy(np.ascontiguousarray(values, dtype=np.float64)).to(device)
-        return cls.from_device_coo(m, coords_d, values_d, eps)
+        return cls.from_device_coo(m, coords_d, values_d, eps, cluster_sizes)
 
     @classmethod
-    def from_device_coo(cls, m: int, coords: torch.Tensor, values: torch.Tensor, eps: float = EPS_BACKGROUND):
+    def from_device_coo(cls, m: int, coords: torch.Tensor, values: torch.Tensor, eps: float = EPS_BACKGROUND,
+                        cluster_sizes=None):
+        """cluster_sizes: number of rows of each consecutive METIS cluster of the batch (a hint
+        for the LDS tiling; any value is correct, good ones make every gather an LDS read)."""
         self = cls()
+        self.cluster_sizes = cluster_sizes
         device = coords.device
         nnz_in = int(coords.shape[0])
         if nnz_in and (int(coords.min()) < 0 or int(coords.max()) >= m):
@@ -110,8 +199,68 @@ class ClusterBatch:
         self.val = val[:nnz].clone()
         self.valT = None if symmetric else valT[:nnz].clone()
         self.device = device
+        self._windows = plan_windows(m, cluster_sizes)
+        self._tiles = {}
+        self._window_ranges = None
         self._prepare(eps)
         return self
+
+    def _in_window_ranges(self):
+        """Per row: positions [lo, hi) of its entries whose column lies in the row's window, the
+        number of its other entries and the first two of those (column, val, valT as float bits);
+        computed once on the device, kept on the host."""
+        if self._window_ranges is None:
+            m, dev = self.m, self.device
+            wb = torch.empty(m, dtype=torch.int64, device=dev)
+            we = torch.empty(m, dtype=torch.int64, device=dev)
+            for a, b in self._windows:
+                wb[a:b] = a
+                we[a:b] = b
+            p0, p1 = self.rowptr[:-1], self.rowptr[1:]
+            rows = torch.repeat_interleave(torch.arange(m, device=dev), p1 - p0)
+            keys = rows * m + self.colidx.to(torch.int64)        # ascending: CSR order
+            base = torch.arange(m, device=dev, dtype=torch.int64) * m
+            lo = torch.searchsorted(keys, base + wb)
+            hi = torch.searchsorted(keys, base + we)
+            n_out = (lo - p0) + (p1 - hi)
+            # positions of the first two outside entries: before the window first, then after it
+            nb = lo - p0
+            pos0 = torch.where(nb > 0, p0, hi)
+            pos1 = torch.where(nb > 1, p0 + 1, torch.where(nb == 1, hi, hi + 1))
+            last = max(self.nnz - 1, 0)
+            pos0c, pos1c = pos0.clamp(0, last), pos1.clamp(0, last)
+            valT = self.valT if self.valT is not None else self.val
+            bits = lambda t: t.view(torch.int32).to(torch.int64)
+            has0, has1 = n_out > 0, n_out > 1
+            zero = torch.zeros_like(lo)
+            rec = torch.stack([torch.where(has0, self.colidx[pos0c].to(torch.int64), zero),
+                               torch.where(has1, self.colidx[pos1c].to(torch.int64), zero),
+                               torch.where(has0, bits(self.val[pos0c]), zero),
+                               torch.where(has0, bits(valT[pos0c]), zero),
+                               torch.where(has1, bits(self.val[pos1c]), zero),
+                               torch.where(has1, bits(valT[pos1c]), zero)], dim=1) if self.nnz else \
+                torch.zeros(m, 6, dtype=torch.int64, device=dev)
+            self._window_ranges = tuple(t.cpu().numpy() for t in (lo, hi, n_out, rec))
+        return self._window_ranges
+
+    def tiles(self, n_slabs: int):
+        """(device tiling buffer, descriptor count, largest window) for the tiled kernel, cached per slab count."""
+        hit = self._tiles.get(n_slabs)
+        if hit is None:
+            if self.nnz >= 2 ** 31:
+                raise ValueError("the tiled kernel needs nnz < 2^31")
+            lo, hi, n_out, out_rec = self._in_window_ranges()
+            desc, recs = plan_tiles(self._windows, lo, hi, n_out, out_rec, n_slabs)
+            assert recs.shape[0] == self.m
+            n_loose = int(sum(d[1] - d[0] for d in desc if d[4] < 0))
+            if n_loose > 0.05 * self.m:   # too many rows reach outside their window: tiling does not pay
+                self._tiles[n_slabs] = (None, 0, 0)
+                return self._tiles[n_slabs]
+            buf = np.concatenate([desc.ravel(), recs.ravel()]).astype(np.int32)
+            rows = max(b - a for a, b in self._windows)
+            hit = (torch.from_numpy(buf).to(self.device), int(desc.shape[0]), int(rows))
+            self._tiles[n_slabs] = hit
+        return hit
 
     def _prepare(self, eps):
         m, device = self.m, self.device
@@ -139,22 +288,29 @@ class ClusterBatch:
             Y = Y.float().contiguous()
         loss = torch.empty((), dtype=torch.float64, device=self.device)
         grad = torch.empty_like(Y) if want_grad else None
-        nbytes = lib.sparc_lap_workspace_bytes(self.m, k)
+        kp = 16 if k <= 16 else (32 if k <= 32 else 64)
+        tiles, ntiles, tile_rows = None, 0, 0
+        if self.use_tiles and ((want_grad and kp >= 32) or (not want_grad and kp == 64)):
+            tiles, ntiles, tile_rows = self.tiles(kp // 32 if want_grad else 1)
+        nbytes = lib.sparc_lap_workspace_bytes(self.m, k, ntiles)
         ws = Workspace.get(nbytes, self.device)
         with torch.cuda.device(self.device):
             check(lib.sparc_lap_fwd(self.m, self.nnz, _ptr(self.rowptr), _ptr(self.colidx), _ptr(self.val),
                                     _ptr(self.valT), _ptr(self.rowc), _ptr(self.coupling), k, k, _ptr(Y), _ptr(loss),
-                                    _ptr(grad), _ptr(ws), nbytes, _stream()), "sparc_lap_fwd")
+                                    _ptr(grad), _ptr(tiles), ntiles, tile_rows, _ptr(ws), nbytes, _stream()),
+                  "sparc_lap_fwd")
         return loss, grad
 
-    def spmm(self, X: torch.Tensor, add: torch.Tensor | None = None, transpose: bool = False) -> torch.Tensor:
-        """Z = A X (+ add); width of X must be 16, 32, 64 or 128."""
+    def spmm(self, X: torch.Tensor, add: torch.Tensor | None = None, transpose: bool = False,
+             tiled: bool = False) -> torch.Tensor:
+        """Z = A X (+ add); width of X must be 16, 32, 64 or 128 (tiled: 64)."""
         X = X.contiguous()
         Z = torch.empty_like(X)
         v = self.val if (not transpose or self.valT is None) else self.valT
+        tiles, ntiles, tile_rows = self.tiles(1) if tiled else (None, 0, 0)
         with torch.cuda.device(self.device):
             check(lib.sparc_spmm(self.m, self.nnz, _ptr(self.rowptr), _ptr(self.colidx), _ptr(v), int(X.shape[1]),
-                                 _ptr(X), _ptr(add), _ptr(Z), _stream()), "sparc_spmm")
+                                 _ptr(X), _ptr(add), _ptr(Z), _ptr(tiles), ntiles, tile_rows, _stream()), "sparc_spmm")
         return Z
 
     def nbytes(self) -> int:

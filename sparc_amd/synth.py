@@ -55,17 +55,18 @@ def planted_cluster_graph(n: int, n_edges: int, n_clusters: int, device, frac_in
     return DeviceGraph(n, indptr, cols.contiguous(), data), bounds
 
 
-def cluster_batches(bounds: torch.Tensor, bsize: int, seed: int = 0):
+def cluster_batches(bounds: torch.Tensor, bsize: int, seed: int = 0, return_clusters: bool = False):
     """Node lists of the training batches: the clusters are shuffled (np.random.shuffle in
     src/utils.py:75) and concatenated `bsize` at a time (:76-80)."""
     b = bounds.cpu().numpy()
     n_clusters = len(b) - 1
     order = np.random.RandomState(seed).permutation(n_clusters)
-    batches = []
+    batches, clusters = [], []
     for st in range(0, n_clusters, bsize):
         ids = order[st:st + bsize]
+        clusters.append(ids)
         batches.append(np.concatenate([np.arange(b[c], b[c + 1], dtype=np.int32) for c in ids]))
-    return batches
+    return (batches, clusters) if return_clusters else batches
 
 
 def block_features(node_ids: np.ndarray, bounds: torch.Tensor, din: int, n_blocks: int, seed: int = 0) -> torch.Tensor:

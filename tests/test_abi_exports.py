@@ -30,8 +30,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_workspace_queries_without_gpu():
     from sparc_amd._lib import lib
-    assert lib.sparc_lap_workspace_bytes(1000, 64) >= 3 * 1000 * 128 * 4
-    assert lib.sparc_lap_workspace_bytes(1000, 65) == 0          # k out of range
+    assert lib.sparc_lap_workspace_bytes(1000, 64, 0) >= 3 * 1000 * 128 * 4
+    assert lib.sparc_lap_workspace_bytes(1000, 65, 0) == 0          # k out of range
     assert lib.sparc_gram_workspace_bytes(1000, 64) > 0
     assert lib.sparc_affinity_prep_workspace_bytes(1000, 5000) > 0
     assert lib.sparc_csr_build_workspace_bytes(1000, 5000) > 0
@@ -40,7 +40,7 @@ def test_workspace_queries_without_gpu():
 
 def test_bad_arguments_are_rejected_before_any_launch():
     from sparc_amd._lib import lib
-    assert lib.sparc_spmm(-1, 0, None, None, None, 64, None, None, None, None) == -1
+    assert lib.sparc_spmm(-1, 0, None, None, None, 64, None, None, None, None, 0, 0, None) == -1
     assert lib.sparc_gram(10, 65, None, 65, None, 65, None, None, 0, None) == -1
     assert lib.sparc_orth_apply(0, 8, None, 8, None, 0, None, 8, None) == -1
 

@@ -140,6 +140,50 @@ def test_lap_loss_and_grad_match_oracle(dev, k, flavour):
     assert rel(loss.item(), ld) < TOL
 
 
+@pytest.mark.parametrize("k", [20, 32, 47, 64])
+def test_lap_tiled_equals_row_kernel_and_oracle(dev, k):
+    """LDS-tiled kernel with cluster windows, with windows that cut clusters, and the row kernel."""
+    from sparc_amd.graph import ClusterBatch
+    rng = np.random.default_rng(7 + k)
+    sizes = [130, 40, 333, 700, 1, 96]            # one cluster larger than a window
+    m = sum(sizes)
+    lab = np.repeat(np.arange(len(sizes)), sizes)
+    P = np.where(lab[:, None] == lab[None, :], 0.05, 0.002)
+    D = np.triu(rng.random((m, m)) < P, 1).astype(np.float64)
+    D = D + D.T + np.eye(m)
+    s = O.as_support_tuple(O.row_normalize_diag_enhance(sp.csr_matrix(D), 0.01))
+    Y = rng.standard_normal((m, k)).astype(np.float32)
+    Yd = torch.tensor(Y, device=dev)
+    A, _ = O.csr_from_support(s)
+    loss_o, g_o, _, _ = O.lap_forward_operator(A, O.affinity_prep_operator(A), Y.astype(np.float64))
+    for hint in (sizes, None, [m // 3, m - m // 3]):
+        b = ClusterBatch.from_support(s, dev, cluster_sizes=hint)
+        assert len(b._windows) >= 2
+        loss, grad = b.lap(Yd, True)
+        assert rel(loss.item(), loss_o) < TOL and rel(grad.cpu().numpy(), g_o) < TOL
+        lv, _ = b.lap(Yd, False)
+        assert rel(lv.item(), loss_o) < TOL
+    try:
+        ClusterBatch.use_tiles = False
+        loss_r, grad_r = b.lap(Yd, True)
+    finally:
+        ClusterBatch.use_tiles = True
+    assert rel(loss_r.item(), loss.item()) < 1e-6 and rel(grad_r.cpu().numpy(), grad.cpu().numpy()) < 1e-5
+
+
+def test_spmm_tiled_matches_scipy(dev):
+    from sparc_amd.graph import ClusterBatch
+    rng = np.random.default_rng(3)
+    m = 1500
+    s = random_support(m, 0.01, rng, "enh")
+    b = ClusterBatch.from_support(s, dev, cluster_sizes=[500, 400, 600])
+    A, At = O.csr_from_support(s)
+    X = rng.standard_normal((m, 64)).astype(np.float32)
+    Xd = torch.tensor(X, device=dev)
+    assert rel(b.spmm(Xd, tiled=True).cpu().numpy(), A @ X.astype(np.float64)) < 1e-5
+    assert rel(b.spmm(Xd, add=Xd, transpose=True, tiled=True).cpu().numpy(), X + At @ X.astype(np.float64)) < 1e-5
+
+
 def test_lap_isolated_nodes_and_empty_rows(dev):
     from sparc_amd.graph import ClusterBatch
     m = 40
