@@ -102,13 +102,27 @@ class SpectralTrainer:
         self._batches = {}
 
     # -- the reference's two helpers, returning device-resident operators -------------------
-    def _get_support_matrix(self, support) -> ClusterBatch:
+    def _get_support_matrix(self, support, cluster_sizes=None) -> ClusterBatch:
         key = id(support)
         hit = self._batches.get(key)
         if hit is None or hit[0] is not support:
-            hit = (support, ClusterBatch.from_support(support, self.device))
+            hit = (support, ClusterBatch.from_support(support, self.device, cluster_sizes=cluster_sizes))
             self._batches[key] = hit
         return hit[1]
+
+    def _cluster_sizes(self):
+        """Row counts of the METIS clusters inside every training batch, when `parts` (the shuffled
+        cluster list) and spectral.bsize describe the batches (src/utils.py:76-80); a hint for the
+        LDS tiling only."""
+        bsize = self.spectral_config.get("bsize")
+        try:
+            sizes = [len(p) for p in self.parts]
+            out = [sizes[st:st + bsize] for st in range(0, len(sizes), bsize)]
+            ok = len(out) == len(self.features_batches) and all(
+                sum(o) == int(f.shape[0]) for o, f in zip(out, self.features_batches))
+            return out if ok else None
+        except Exception:
+            return None
 
     def _get_valid_affinity_matrix(self, W: ClusterBatch, X=None) -> ClusterBatch:
         return W  # the affinity vectors were prepared together with the CSR
@@ -129,9 +143,11 @@ class SpectralTrainer:
 
         # one-time: features and supports to the device
         feats = [f.to(self.device, dtype=torch.float32) for f in self.features_batches]
-        sup = [self._get_support_matrix(s) for s in self.support_batches]
+        sizes = self._cluster_sizes()
+        sup = [self._get_support_matrix(s, sizes[i] if sizes else None).warm(k)
+               for i, s in enumerate(self.support_batches)]
         vfeats = [f.to(self.device, dtype=torch.float32) for f in self.val_features_batches]
-        vsup = [self._get_support_matrix(s) for s in self.val_support_batches]
+        vsup = [self._get_support_matrix(s).warm(k, training=False) for s in self.val_support_batches]
 
         min_val_loss = 1000000000
         batches = len(feats)

@@ -81,112 +81,143 @@ __global__ void gram_reduce(int kk, int nparts, const double* __restrict__ slab,
     G[e] = (t0 + t1) + (t2 + t3);
 }
 
-// Single workgroup.  LDS images: R (Gram, then its Cholesky factor, upper), X = R^-1, Q.
+constexpr int KLD = SPARC_MAX_K + 1;  // leading dimension of the k x k LDS images (bank-conflict free columns)
+
+// Single workgroup of 4 waves.  LDS images (padded leading dimension): R (Gram, then its Cholesky
+// factor, upper), X = R^-1, T (top rows of Yt), Q (Yt[top] X and its sign-tracking LU).
 __global__ __launch_bounds__(256) void orth_weights_kernel(int64_t m, int k, const double* __restrict__ G,
                                                            const float* __restrict__ Yt, int64_t ld,
                                                            const int32_t* __restrict__ top_idx, int mode,
                                                            float* __restrict__ Wo, double* __restrict__ Rc_out,
                                                            double* __restrict__ Rinv_out, double* __restrict__ signs_out,
                                                            int32_t* __restrict__ info) {
-    __shared__ double R[SPARC_MAX_K * SPARC_MAX_K];
-    __shared__ double X[SPARC_MAX_K * SPARC_MAX_K];
-    __shared__ double Q[SPARC_MAX_K * SPARC_MAX_K];
+    __shared__ double R[SPARC_MAX_K * KLD];
+    __shared__ double X[SPARC_MAX_K * KLD];
+    __shared__ double Q[SPARC_MAX_K * KLD];
+    __shared__ double T[SPARC_MAX_K * KLD];
     __shared__ double sg[SPARC_MAX_K];
     __shared__ int bad;
     const int tid = threadIdx.x;
+    const int ty = tid >> 4, tx = tid & 15;  // 16 x 16 thread grid over the trailing matrix
     if (tid == 0) bad = 0;
-    for (int e = tid; e < k * k; e += 256) { R[e] = G[e]; X[e] = 0.0; }
+    for (int e = tid; e < k * k; e += 256) {
+        const int i = e / k, j = e % k;
+        R[i * KLD + j] = G[e];
+        X[i * KLD + j] = 0.0;
+        double y = 0.0;
+        if (mode == 0) {
+            const int64_t row = top_idx ? top_idx[i] : i;
+            if (row < m) y = static_cast<double>(Yt[row * ld + j]);
+        }
+        T[i * KLD + j] = y;  // top rows of Yt
+    }
     __syncthreads();
 
-    // Cholesky, upper: G = R^T R
+    // Cholesky, upper: G = R^T R.  Two barriers per column: scale the pivot row, update the trailing
+    // triangle (every thread derives the pivot itself, so there is no separate pivot phase).
     for (int j = 0; j < k; ++j) {
-        if (tid == 0) {
-            double piv = R[j * k + j];
-            if (!(piv > 0.0)) { if (!bad) bad = j + 1; piv = 1e-300; }
-            R[j * k + j] = sqrt(piv);
+        double piv = R[j * KLD + j];
+        if (!(piv > 0.0)) {
+            if (tid == 0 && !bad) bad = j + 1;
+            piv = 1e-300;
         }
+        const double inv_dj = 1.0 / sqrt(piv);
+        __syncthreads();  // everyone has read the pivot before it is overwritten
+        for (int c = j + tid; c < k; c += 256) R[j * KLD + c] = (c == j) ? piv * inv_dj : R[j * KLD + c] * inv_dj;
         __syncthreads();
-        const double dj = R[j * k + j];
-        for (int c = j + 1 + tid; c < k; c += 256) R[j * k + c] /= dj;
-        __syncthreads();
-        const int n = k - j - 1;
-        for (int e = tid; e < n * n; e += 256) {
-            const int a = j + 1 + e / n, b = j + 1 + e % n;
-            if (a <= b) R[a * k + b] -= R[j * k + a] * R[j * k + b];
+        for (int a2 = j + 1 + ty; a2 < k; a2 += 16) {
+            const double f = R[j * KLD + a2];
+            for (int b2 = j + 1 + tx; b2 < k; b2 += 16)
+                if (a2 <= b2) R[a2 * KLD + b2] -= f * R[j * KLD + b2];
         }
         __syncthreads();
     }
     for (int e = tid; e < k * k; e += 256)
-        if (e / k > e % k) R[e] = 0.0;
+        if (e / k > e % k) R[(e / k) * KLD + e % k] = 0.0;
     __syncthreads();
 
-    // X = R^-1 (upper), one column per thread
+    // X = R^-1 (upper), one column per thread (its own column: no synchronisation inside)
     if (tid < k) {
         const int c = tid;
-        X[c * k + c] = 1.0 / R[c * k + c];
+        X[c * KLD + c] = 1.0 / R[c * KLD + c];
         for (int i = c - 1; i >= 0; --i) {
-            double t = 0.0;
-            for (int l = i + 1; l <= c; ++l) t += R[i * k + l] * X[l * k + c];
-            X[i * k + c] = -t / R[i * k + i];
+            double tsum = 0.0;
+            for (int l = i + 1; l <= c; ++l) tsum += R[i * KLD + l] * X[l * KLD + c];
+            X[i * KLD + c] = -tsum / R[i * KLD + i];
         }
     }
     __syncthreads();
 
-    // Householder signs from the modified LU of Q = Yt[top] X
     if (mode == 0) {
+        // Q = Yt[top] X
         for (int e = tid; e < k * k; e += 256) {
-            const int a = e / k, b = e % k;
-            const int64_t row = top_idx ? top_idx[a] : a;
-            double t = 0.0;
-            if (row < m)
-                for (int l = 0; l <= b; ++l) t += static_cast<double>(Yt[row * ld + l]) * X[l * k + b];
-            Q[e] = t;
+            const int a2 = e / k, b2 = e % k;
+            double tsum = 0.0;
+            for (int l = 0; l <= b2; ++l) tsum += T[a2 * KLD + l] * X[l * KLD + b2];
+            Q[a2 * KLD + b2] = tsum;
         }
         __syncthreads();
+        // Householder signs from the modified LU of Q, two barriers per column
         for (int i = 0; i < k; ++i) {
-            if (tid == 0) {
-                const double s = Q[i * k + i] > 0.0 ? -1.0 : 1.0;
-                sg[i] = s;
-                Q[i * k + i] -= s;
-            }
+            const double qii = Q[i * KLD + i];
+            const double sgn = qii > 0.0 ? -1.0 : 1.0;
+            const double inv_piv = 1.0 / (qii - sgn);
             __syncthreads();
-            const double piv = Q[i * k + i];
-            for (int a = i + 1 + tid; a < k; a += 256) Q[a * k + i] /= piv;
+            if (tid == 0) sg[i] = sgn;
+            for (int a2 = i + 1 + tid; a2 < k; a2 += 256) Q[a2 * KLD + i] *= inv_piv;
             __syncthreads();
-            const int n = k - i - 1;
-            for (int e = tid; e < n * n; e += 256) {
-                const int a = i + 1 + e / n, b = i + 1 + e % n;
-                Q[a * k + b] -= Q[a * k + i] * Q[i * k + b];
+            for (int a2 = i + 1 + ty; a2 < k; a2 += 16) {
+                const double f = Q[a2 * KLD + i];
+                for (int b2 = i + 1 + tx; b2 < k; b2 += 16) Q[a2 * KLD + b2] -= f * Q[i * KLD + b2];
             }
             __syncthreads();
         }
-    } else {
-        if (tid < k) sg[tid] = 1.0;
-        __syncthreads();
+    } else if (tid < k) {
+        sg[tid] = 1.0;
     }
+    __syncthreads();
 
     const double sq = sqrt(static_cast<double>(m));
     for (int e = tid; e < k * k; e += 256) {
         const int i = e / k, j = e % k;
-        Wo[e] = static_cast<float>(sq * sg[i] * X[e] * sg[j]);
-        Rc_out[e] = R[e];
-        Rinv_out[e] = X[e];
+        const double x = X[i * KLD + j];
+        Wo[e] = static_cast<float>(sq * sg[i] * x * sg[j]);
+        Rc_out[e] = R[i * KLD + j];
+        Rinv_out[e] = x;
     }
     if (tid < k) signs_out[tid] = sg[tid];
     if (tid == 0) *info = bad;
 }
 
-// C = op(A) op(B) for k x k matrices in LDS (row-major, stride k); out may not alias.
+// C = scale * op(A) op(B) for k x k matrices in LDS (row-major, leading dimension KLD); C may not
+// alias A or B.  Each thread owns a 4 x 4 block of C.
 __device__ void mm_kk(int k, const double* A, bool ta, const double* B, bool tb, double* C, double scale) {
-    for (int e = threadIdx.x; e < k * k; e += 256) {
-        const int i = e / k, j = e % k;
-        double t = 0.0;
+    const int nb = (k + 3) / 4;
+    for (int blk = threadIdx.x; blk < nb * nb; blk += 256) {
+        const int i0 = (blk / nb) * 4, j0 = (blk % nb) * 4;
+        double acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
         for (int l = 0; l < k; ++l) {
-            const double a = ta ? A[l * k + i] : A[i * k + l];
-            const double b = tb ? B[j * k + l] : B[l * k + j];
-            t += a * b;
+            double av[4], bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ii = min(i0 + i, k - 1), jj = min(j0 + i, k - 1);
+                av[i] = ta ? A[l * KLD + ii] : A[ii * KLD + l];
+                bv[i] = tb ? B[jj * KLD + l] : B[l * KLD + jj];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += av[i] * bv[j];
         }
-        C[e] = scale * t;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (i0 + i < k && j0 + j < k) C[(i0 + i) * KLD + j0 + j] = scale * acc[i][j];
     }
     __syncthreads();
 }
@@ -197,18 +228,18 @@ __global__ __launch_bounds__(256) void orth_weights_bwd_kernel(int64_t m, int k,
                                                                const double* __restrict__ Rc, const double* __restrict__ Rinv,
                                                                const double* __restrict__ signs, int mode,
                                                                float* __restrict__ H) {
-    __shared__ double M[SPARC_MAX_K * SPARC_MAX_K];   // Rc^-1
-    __shared__ double A[SPARC_MAX_K * SPARC_MAX_K];
-    __shared__ double B[SPARC_MAX_K * SPARC_MAX_K];
-    __shared__ double L[SPARC_MAX_K * SPARC_MAX_K];   // Rc (upper); L = Rc^T
+    __shared__ double M[SPARC_MAX_K * KLD];   // Rc^-1
+    __shared__ double A[SPARC_MAX_K * KLD];
+    __shared__ double B[SPARC_MAX_K * KLD];
+    __shared__ double L[SPARC_MAX_K * KLD];   // Rc (upper); L = Rc^T
     const int tid = threadIdx.x;
     const double sq = sqrt(static_cast<double>(m));
     for (int e = tid; e < k * k; e += 256) {
         const int i = e / k, j = e % k;
-        M[e] = Rinv[e];
-        L[e] = Rc[e];
+        M[i * KLD + j] = Rinv[e];
+        L[i * KLD + j] = Rc[e];
         const double s = (mode == 0) ? signs[i] * signs[j] : 1.0;
-        A[e] = (i <= j) ? sq * s * gWo[e] : 0.0;  // Mbar (upper part only: M is upper triangular)
+        A[i * KLD + j] = (i <= j) ? sq * s * gWo[e] : 0.0;  // Mbar (upper part only: M is upper triangular)
     }
     __syncthreads();
     mm_kk(k, A, false, M, true, B, 1.0);    // B = Mbar M^T
@@ -216,20 +247,21 @@ __global__ __launch_bounds__(256) void orth_weights_bwd_kernel(int64_t m, int k,
     // Lbar = tril(Rbar^T): B[i][j] = Rbar[j][i] for i >= j
     for (int e = tid; e < k * k; e += 256) {
         const int i = e / k, j = e % k;
-        B[e] = (i >= j) ? A[j * k + i] : 0.0;
+        B[i * KLD + j] = (i >= j) ? A[j * KLD + i] : 0.0;
     }
     __syncthreads();
     mm_kk(k, L, false, B, false, A, 1.0);   // A = L^T Lbar = Rc Lbar
     for (int e = tid; e < k * k; e += 256) {
         const int i = e / k, j = e % k;
-        A[e] = (i > j) ? A[e] : (i == j ? 0.5 * A[e] : 0.0);  // Phi
+        const double v = A[i * KLD + j];
+        A[i * KLD + j] = (i > j) ? v : (i == j ? 0.5 * v : 0.0);  // Phi
     }
     __syncthreads();
     mm_kk(k, M, false, A, false, B, 1.0);   // B = M Phi
     mm_kk(k, B, false, M, true, A, 1.0);    // A = Gbar = M Phi M^T
     for (int e = tid; e < k * k; e += 256) {
         const int i = e / k, j = e % k;
-        H[e] = static_cast<float>(A[e] + A[j * k + i]);
+        H[e] = static_cast<float>(A[i * KLD + j] + A[j * KLD + i]);
     }
 }
 

@@ -36,6 +36,28 @@ struct RowPre {  // what the epilogue reads of its own row, requested before the
     float4 x0, rc0, rc1;
 };
 
+struct LapConst {  // per-lane constants of the Laplacian epilogue: rows of M1 / M2 and the 3x3 coupling
+    float4 ma, mb, mc;
+    float cf[9];
+};
+
+template <int EPI>
+__device__ __forceinline__ LapConst lap_const(const SpmmArgs& a, const int kp, const int cl, const bool right) {
+    LapConst c;
+    c.ma = c.mb = c.mc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) c.cf[i] = 0.f;
+    if (EPI == EPI_LAP_SINGLE || EPI == EPI_LAP_DUAL) {
+        const float* Mb = a.M12 + (right ? 3 * kp : 0) + cl;
+        c.ma = *reinterpret_cast<const float4*>(Mb);
+        c.mb = *reinterpret_cast<const float4*>(Mb + kp);
+        c.mc = *reinterpret_cast<const float4*>(Mb + 2 * kp);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) c.cf[i] = a.M12[6 * kp + i];
+    }
+    return c;
+}
+
 template <int EPI>
 __device__ __forceinline__ RowPre row_preload(const SpmmArgs& a, const int64_t row, const int wtot, const int gcol) {
     RowPre r;
@@ -61,8 +83,8 @@ __device__ __forceinline__ double rows_sum(double v) {
 template <bool DUAL, int EPI, int ROWS = 1>
 __device__ __forceinline__ void row_epilogue(const SpmmArgs& a, const int64_t row, const int lane, const bool owner,
                                              const int half, const int kp, const int wtot, const int gcol,
-                                             const int cl, const bool right, const RowPre& pre, float4 acc,
-                                             double& wloss) {
+                                             const int cl, const bool right, const RowPre& pre, const LapConst& lc,
+                                             float4 acc, double& wloss) {
     const int64_t ro = row * wtot + gcol;
     if (EPI == EPI_STORE) {
         if (owner) *reinterpret_cast<float4*>(a.out + ro) = acc;
@@ -108,15 +130,12 @@ __device__ __forceinline__ void row_epilogue(const SpmmArgs& a, const int64_t ro
         const float4 rc0 = pre.rc0, rc1 = pre.rc1, x0 = pre.x0;
         const bool isolated = rc0.x < 0.f;
         const float irho = fabsf(rc0.x);
-        const float* Mb = a.M12 + (right ? 3 * kp : 0) + cl;
-        const float* Cf = a.M12 + 6 * kp;  // the 3x3 coupling, row-major
+        const float* Cf = lc.cf;  // the 3x3 coupling, row-major
         // diagonal of U C V^T for this row
         const float ldiag = (Cf[0] + Cf[1] * rc1.z + Cf[2] * rc1.w) + rc1.x * (Cf[3] + Cf[4] * rc1.z + Cf[5] * rc1.w) +
                             rc1.y * (Cf[6] + Cf[7] * rc1.z + Cf[8] * rc1.w);
         const float u1 = right ? rc1.z : rc1.x, u2 = right ? rc1.w : rc1.y;
-        const float4 ma = *reinterpret_cast<const float4*>(Mb);
-        const float4 mb = *reinterpret_cast<const float4*>(Mb + kp);
-        const float4 mc = *reinterpret_cast<const float4*>(Mb + 2 * kp);
+        const float4 ma = lc.ma, mb = lc.mb, mc = lc.mc;
         float4 t;
         t.x = (isolated ? 0.f : acc.x - rc0.y * x0.x) + ((ma.x + u1 * mb.x + u2 * mc.x) - ldiag * x0.x);
         t.y = (isolated ? 0.f : acc.y - rc0.y * x0.y) + ((ma.y + u1 * mb.y + u2 * mc.y) - ldiag * x0.y);
@@ -146,7 +165,7 @@ __device__ __forceinline__ void row_epilogue(const SpmmArgs& a, const int64_t ro
                     if (cl + q < a.k) gp[q] = gy[q];
             }
         }
-        wloss += wave_sum(dot);
+        wloss += dot;  // per lane; summed over the wave once, by the caller
     }
 }
 
@@ -219,7 +238,8 @@ __device__ __forceinline__ void wave_row_global(const SpmmArgs& a, const int64_t
     const bool right = DUAL && lr >= HALF;
     const int kp = DUAL ? W / 2 : W;
     const int cl = (DUAL ? (lr % HALF) : lr) * 4;
-    row_epilogue<DUAL, EPI>(a, row, lane, g == 0, HALF, kp, W, lr * 4, cl, right, pre, acc, wloss);
+    const LapConst lc = lap_const<EPI>(a, kp, cl, right);
+    row_epilogue<DUAL, EPI>(a, row, lane, g == 0, HALF, kp, W, lr * 4, cl, right, pre, lc, acc, wloss);
 }
 
 template <int LR, bool DUAL, int EPI>
@@ -234,6 +254,7 @@ __global__ __launch_bounds__(256) void spmm_rows(const SpmmArgs a) {
     }
     if (EPI == EPI_LAP_SINGLE || EPI == EPI_LAP_DUAL) {
         __shared__ double wl[4];
+        wloss = wave_sum(wloss);
         if (lane == 0) wl[wave] = wloss;
         __syncthreads();
         if (threadIdx.x == 0) a.loss_part[blk] = (wl[0] + wl[1]) + (wl[2] + wl[3]);
@@ -334,6 +355,7 @@ __global__ __launch_bounds__(TILED_THREADS) void spmm_tiled(const SpmmArgs a) {
         }
         if (EPI == EPI_LAP_SINGLE || EPI == EPI_LAP_DUAL) {
             __shared__ double gw[TILED_WAVES];
+            gl = wave_sum(gl);
             if (lane == 0) gw[wave] = gl;
             __syncthreads();
             if (threadIdx.x == 0) {
@@ -370,6 +392,7 @@ __global__ __launch_bounds__(TILED_THREADS) void spmm_tiled(const SpmmArgs a) {
         info[i] = reinterpret_cast<const int4*>(a.rowinfo)[static_cast<int64_t>(q_begin) * 3 + i];
     const char* tile_bytes = reinterpret_cast<const char*>(tile);
     const int lr16 = lr * 16;
+    const LapConst lc = lap_const<EPI>(a, kp, cl, right);
     __syncthreads();  // the window and the records have landed (the barrier waits for the LDS copies)
 
     // A wave owns slots wave, wave + 16, ... (4 rows each).  The entries and epilogue operands of a
@@ -447,13 +470,14 @@ __global__ __launch_bounds__(TILED_THREADS) void spmm_tiled(const SpmmArgs a) {
             acc.z += __shfl_xor(acc.z, 32); acc.w += __shfl_xor(acc.w, 32);
         }
         row_epilogue<DUAL, EPI, 4>(a, ri.x, lane, ri.x >= 0 && (!lng || g == 0), 8, kp, wtot, gcol, cl, right, cur.pre,
-                                   acc, wloss);
+                                   lc, acc, wloss);
         cur = nxt;
         nxt = nn;
     }
 
     if (EPI == EPI_LAP_SINGLE || EPI == EPI_LAP_DUAL) {
         __shared__ double wl[TILED_WAVES];
+        wloss = wave_sum(wloss);
         if (lane == 0) wl[wave] = wloss;
         __syncthreads();
         if (threadIdx.x == 0) {

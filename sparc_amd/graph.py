@@ -275,6 +275,13 @@ class ClusterBatch:
                                           _ptr(ws), nbytes, _stream()), "sparc_affinity_prep")
         self.d, self.cw, self.rho = vec[0], vec[1], vec[2]
 
+    def warm(self, k: int, training: bool = True):
+        """Build the tiling for spectral dimension k now (it is otherwise built on first use)."""
+        kp = 16 if k <= 16 else (32 if k <= 32 else 64)
+        if self.use_tiles and ((training and kp >= 32) or (not training and kp == 64)):
+            self.tiles(kp // 32 if training else 1)
+        return self
+
     # ---- per-step work -------------------------------------------------------------------
     def lap(self, Y: torch.Tensor, want_grad: bool):
         """loss (float64 0-d tensor) and d loss / d Y (or None) for is_normalized=True."""
