@@ -201,7 +201,8 @@ def main():
                        "batches_per_gpu": nb, "prep_seconds_per_batch": t_prep / max(nb, 1),
                        "parallelism": f"dp{world} (cluster batches sharded, flat-gradient all-reduce)",
                        "mean_loss": final_loss},
-            "roofline": {"bound": "hbm", "kernel": "spmm_rows<dual, add-x0> (inner passes of the Laplacian chain)",
+            "roofline": {"bound": "hbm", "kernel": "spmm_tiled<dual, add-x0> (inner passes of the Laplacian chain; "
+                                                   "spmm_rows when a batch has no tiling)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "avg_kernel_us": kern_ms * 1e3, "launches_timed": int(launches.value),
                          "algorithmic_bytes_per_launch": per_launch},

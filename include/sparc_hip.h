@@ -161,6 +161,23 @@ int sparc_orth_weights_bwd(int64_t m, int k, const double* gWo, const double* Rc
                            const double* Rinv, const double* signs, int mode, float* H,
                            sparc_stream_t stream);
 
+/* ---- MLP backward helpers ------------------------------------------------------------------------
+ * The SpectralNet MLP is Linear+ReLU x3, Linear+Tanh (src/SpectralTrainer.py:28-39); its wide
+ * products are library GEMMs.  These two replace the elementwise and narrow parts of the autograd
+ * backward (src/SpectralTrainer.py:237):
+ * sparc_act_bwd_bias: gout = g * act'(h) with h the layer's OUTPUT (act 0: ReLU, h > 0 ? g : 0;
+ *                     act 1: Tanh, g (1 - h^2)) and db[n] = column sums of gout (the bias gradient),
+ *                     in one pass over g and h; all three [m][ld*], gout may alias g.
+ * sparc_wgrad_small:  dW = g^T h, g [m][n_out] with n_out <= SPARC_MAX_K, h [m][n_in] with
+ *                     n_in a multiple of 64 and 16-byte aligned rows: the weight gradient of the
+ *                     output layer (f32 MFMA, fixed summation order). */
+size_t sparc_act_bwd_bias_workspace_bytes(int64_t m, int n);
+int sparc_act_bwd_bias(int64_t m, int n, int act, const float* g, int64_t ldg, const float* h, int64_t ldh,
+                       float* gout, int64_t ldo, float* db, void* ws, size_t ws_bytes, sparc_stream_t stream);
+size_t sparc_wgrad_small_workspace_bytes(int n_out, int n_in);
+int sparc_wgrad_small(int64_t m, int n_out, int n_in, const float* g, int64_t ldg, const float* h, int64_t ldh,
+                      float* dW, void* ws, size_t ws_bytes, sparc_stream_t stream);
+
 /* ---- support / degree construction -----------------------------------------------------------
  * Replaces the sparse algebra of preprocess_multicluster / preprocess (src/utils.py:60-137):
  * the induced sub-block adj[pt,:][:,pt] (:83, :126), normalize_adj (:22-27),

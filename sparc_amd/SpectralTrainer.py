@@ -22,7 +22,7 @@ import torch.nn as nn
 import torch.optim as optim
 
 from .graph import ClusterBatch, require_gpu
-from .ops import ORTH_CHOLESKY, ORTH_REFERENCE, LapLoss, OrthApply, OrthWeights
+from .ops import ACT_RELU, ACT_TANH, ORTH_CHOLESKY, ORTH_REFERENCE, LapLoss, LinearAct, OrthApply, OrthWeights
 
 
 class SpectralNetModel(nn.Module):
@@ -56,7 +56,8 @@ class SpectralNetModel(nn.Module):
 
     def embed_pre_orth(self, x: torch.Tensor) -> torch.Tensor:
         for layer in self.layers:
-            x = layer(x)
+            lin, act = layer[0], layer[1]
+            x = LinearAct.apply(x, lin.weight, lin.bias, ACT_TANH if isinstance(act, nn.Tanh) else ACT_RELU)
         return x
 
     def forward(self, x: torch.Tensor, should_update_orth_weights: bool = True, top_idx=None) -> torch.Tensor:
@@ -136,7 +137,7 @@ class SpectralTrainer:
         self.criterion = SpectralNetLoss()
         self.spectral_net = SpectralNetModel(self.architecture, input_dim=self.features_batches[0].shape[1],
                                              device=self.device, orth_mode=self.orth_mode).to(self.device)
-        self.optimizer = optim.Adam(self.spectral_net.parameters(), lr=self.lr)
+        self.optimizer = optim.Adam(self.spectral_net.parameters(), lr=self.lr, fused=True)  # one launch per step
         self.scheduler = optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, mode="min", factor=self.lr_decay,
                                                               patience=self.patience)
         k = self.architecture["output_dim"]

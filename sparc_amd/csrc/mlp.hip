@@ -1,0 +1,273 @@
+// Backward helpers of the SpectralNet MLP (src/SpectralTrainer.py:28-39, autograd at :237):
+// the activation derivative fused with the bias gradient, and the weight gradient of the
+// narrow output layer.  The wide products stay library GEMMs.
+#include "common.h"
+
+namespace {
+
+constexpr int ACT_RELU = 0;
+constexpr int ACT_TANH = 1;
+constexpr int COLSUM_LANES = 16;
+
+template <int ACT>
+__device__ __forceinline__ float act_grad(float g, float h) {
+    if (ACT == ACT_RELU) return h > 0.f ? g : 0.f;
+    return g * (1.f - h * h);
+}
+
+// out = g * act'(h) and the column sums of out over the block's rows.  A row is covered by
+// tpr threads (power of two), VEC columns each; 256 / tpr rows are in flight per iteration.
+// partial is [gridDim.x][n].
+template <int VEC, int ACT>
+__global__ __launch_bounds__(256) void act_bwd_bias_kernel(int64_t m, int n, const float* __restrict__ g, int64_t ldg,
+                                                           const float* __restrict__ h, int64_t ldh,
+                                                           float* __restrict__ out, int64_t ldo,
+                                                           float* __restrict__ partial, int tpr, int64_t rows_per_block) {
+    __shared__ float red[256 * VEC];
+    const int tx = threadIdx.x & (tpr - 1);
+    const int ty = threadIdx.x / tpr;
+    const int rpi = 256 / tpr;
+    const int col = (blockIdx.y * tpr + tx) * VEC;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(m, r0 + rows_per_block);
+    float acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+    if (col < n) {
+#pragma unroll 4
+        for (int64_t r = r0 + ty; r < r1; r += rpi) {
+            if constexpr (VEC == 4) {
+                const float4 gv = *reinterpret_cast<const float4*>(g + r * ldg + col);
+                const float4 hv = *reinterpret_cast<const float4*>(h + r * ldh + col);
+                float4 o;
+                o.x = act_grad<ACT>(gv.x, hv.x);
+                o.y = act_grad<ACT>(gv.y, hv.y);
+                o.z = act_grad<ACT>(gv.z, hv.z);
+                o.w = act_grad<ACT>(gv.w, hv.w);
+                *reinterpret_cast<float4*>(out + r * ldo + col) = o;
+                acc[0] += o.x;
+                acc[1 % VEC] += o.y;
+                acc[2 % VEC] += o.z;
+                acc[3 % VEC] += o.w;
+            } else {
+                const float o = act_grad<ACT>(g[r * ldg + col], h[r * ldh + col]);
+                out[r * ldo + col] = o;
+                acc[0] += o;
+            }
+        }
+    }
+    if (rpi > 1) {  // fold the rows in flight: fixed order
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) red[threadIdx.x * VEC + v] = acc[v];
+        __syncthreads();
+        if (ty == 0) {
+            for (int y = 1; y < rpi; ++y)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc[v] += red[(y * tpr + tx) * VEC + v];
+        }
+    }
+    if (ty == 0 && col < n) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) partial[(int64_t)blockIdx.x * n + col + v] = acc[v];
+    }
+}
+
+// db[c] = sum over the row blocks of partial[b][c]; 64 columns x 16 lanes per workgroup.
+__global__ __launch_bounds__(64 * COLSUM_LANES) void colsum_finish(int nparts, int n, const float* __restrict__ partial,
+                                                                    float* __restrict__ db) {
+    __shared__ float red[COLSUM_LANES][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int lane = threadIdx.x >> 6;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < n) {
+        int b = lane;
+        for (; b + COLSUM_LANES < nparts; b += 2 * COLSUM_LANES) {
+            s0 += partial[(int64_t)b * n + c];
+            s1 += partial[(int64_t)(b + COLSUM_LANES) * n + c];
+        }
+        if (b < nparts) s0 += partial[(int64_t)b * n + c];
+    }
+    red[lane][threadIdx.x & 63] = s0 + s1;
+    __syncthreads();
+    if (lane == 0 && c < n) {
+        float s = 0.f;
+#pragma unroll
+        for (int l = 0; l < COLSUM_LANES; ++l) s += red[l][threadIdx.x & 63];
+        db[c] = s;
+    }
+}
+
+struct ActPlan {
+    int vec, tpr, coltiles, nparts;
+    int64_t rows_per_block;
+};
+
+ActPlan act_plan(int64_t m, int n, bool aligned) {
+    ActPlan p;
+    p.vec = aligned ? 4 : 1;
+    const int per_row = (n + p.vec - 1) / p.vec;
+    p.tpr = 1;
+    while (p.tpr < per_row && p.tpr < 256) p.tpr <<= 1;
+    p.coltiles = (per_row + p.tpr - 1) / p.tpr;
+    const int rpi = 256 / p.tpr;
+    int64_t parts = 512 / p.coltiles;
+    if (parts < 1) parts = 1;
+    int64_t rpb = (m + parts - 1) / parts;
+    rpb = (rpb + rpi - 1) / rpi * rpi;
+    if (rpb < rpi) rpb = rpi;
+    p.rows_per_block = rpb;
+    p.nparts = (int)((m + rpb - 1) / rpb);
+    return p;
+}
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// partial[chunk] = g[rows of chunk]^T h[rows of chunk][64-column block], f32 MFMA 16x16x4.
+// Lane l = (jj = l & 15, kk = l >> 4).  Per step of four rows the lane reads h[row kk][4 jj .. 4 jj + 3]
+// (16 bytes) and g[row kk][16 it + jj]; product tile (it, t) therefore holds the OUTPUT columns
+// 4 j + t, j = 0..15, of the block: register r of lane l is dW[16 it + 4 kk + r][64 blk + 4 jj + t].
+template <int NT>
+__global__ __launch_bounds__(256) void wgrad_small_kernel(int64_t m, int n_out, int n_in, const float* __restrict__ g,
+                                                          int64_t ldg, const float* __restrict__ h, int64_t ldh,
+                                                          float* __restrict__ partial, int64_t rows_per_block) {
+    extern __shared__ float sm[];  // [4 waves][NT * 16][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int jj = lane & 15, kk = lane >> 4;
+    const int blk = blockIdx.x;
+    const int64_t c0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t c1 = min(m, c0 + rows_per_block);
+    const int64_t per_wave = ((c1 - c0 + 3) / 4 + 3) / 4 * 4;  // rows of one wave, a multiple of 4
+    const int64_t w0 = c0 + wave * per_wave;
+    const int64_t w1 = min(c1, w0 + per_wave);
+
+    v4f acc[NT][4];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[a][t] = v4f{0.f, 0.f, 0.f, 0.f};
+
+    const float* hp = h + (int64_t)blk * 64 + 4 * jj;
+#pragma unroll 2
+    for (int64_t rb = w0; rb < w1; rb += 4) {
+        const int64_t r = rb + kk;
+        const bool live = r < w1;
+        float4 hb = make_float4(0.f, 0.f, 0.f, 0.f);
+        float ga[NT];
+        if (live) hb = *reinterpret_cast<const float4*>(hp + r * ldh);
+#pragma unroll
+        for (int a = 0; a < NT; ++a) ga[a] = (live && 16 * a + jj < n_out) ? g[r * ldg + 16 * a + jj] : 0.f;
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+            acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[a], hb.x, acc[a][0], 0, 0, 0);
+            acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[a], hb.y, acc[a][1], 0, 0, 0);
+            acc[a][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[a], hb.z, acc[a][2], 0, 0, 0);
+            acc[a][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[a], hb.w, acc[a][3], 0, 0, 0);
+        }
+    }
+
+    // the four waves' tiles meet in LDS and are added in wave order
+    float* mine = sm + (size_t)wave * NT * 16 * 64;
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float4 v = make_float4(acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]);
+            *reinterpret_cast<float4*>(mine + (16 * a + 4 * kk + r) * 64 + 4 * jj) = v;
+        }
+    __syncthreads();
+    float* out = partial + ((int64_t)blockIdx.y * NT * 16) * n_in + (int64_t)blk * 64;
+    for (int e = threadIdx.x; e < NT * 16 * 64; e += 256) {
+        const float s = ((sm[e] + sm[NT * 16 * 64 + e]) + sm[2 * NT * 16 * 64 + e]) + sm[3 * NT * 16 * 64 + e];
+        out[(int64_t)(e >> 6) * n_in + (e & 63)] = s;
+    }
+}
+
+// dW[i][j] = sum over the chunks of partial[chunk][i][j]
+__global__ __launch_bounds__(256) void wgrad_finish(int nchunks, int n_out, int n_out_pad, int n_in,
+                                                    const float* __restrict__ partial, float* __restrict__ dW) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)n_out * n_in) return;
+    const int i = (int)(e / n_in), j = (int)(e % n_in);
+    const int64_t stride = (int64_t)n_out_pad * n_in;
+    const float* p = partial + (int64_t)i * n_in + j;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int c = 0;
+    for (; c + 3 < nchunks; c += 4) {
+        s0 += p[c * stride];
+        s1 += p[(c + 1) * stride];
+        s2 += p[(c + 2) * stride];
+        s3 += p[(c + 3) * stride];
+    }
+    for (; c < nchunks; ++c) s0 += p[c * stride];
+    dW[e] = (s0 + s1) + (s2 + s3);
+}
+
+constexpr int WGRAD_CHUNKS = 32;
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" size_t sparc_act_bwd_bias_workspace_bytes(int64_t m, int n) {
+    if (m < 0 || n <= 0) return 0;
+    return sparc_align_up((size_t)512 * (size_t)n * sizeof(float)) + 256;
+}
+
+extern "C" int sparc_act_bwd_bias(int64_t m, int n, int act, const float* g, int64_t ldg, const float* h, int64_t ldh,
+                                  float* gout, int64_t ldo, float* db, void* ws, size_t ws_bytes, sparc_stream_t stream) {
+    if (m < 0 || n <= 0 || (act != ACT_RELU && act != ACT_TANH) || !g || !h || !gout || !db || ldg < n || ldh < n || ldo < n)
+        return SPARC_ERR_ARG;
+    if (ws_bytes < sparc_act_bwd_bias_workspace_bytes(m, n) || !ws || (reinterpret_cast<uintptr_t>(ws) & 255)) return SPARC_ERR_WS;
+    if (m == 0) return hipMemsetAsync(db, 0, (size_t)n * sizeof(float), stream) == hipSuccess ? SPARC_OK : SPARC_ERR_LAUNCH;
+    const bool aligned = n % 4 == 0 && ldg % 4 == 0 && ldh % 4 == 0 && ldo % 4 == 0 && aligned16(g) && aligned16(h) && aligned16(gout);
+    const ActPlan p = act_plan(m, n, aligned);
+    float* partial = static_cast<float*>(ws);
+    dim3 grid(p.nparts, p.coltiles);
+#define SPARC_ACT_LAUNCH(V, A)                                                                                         \
+    hipLaunchKernelGGL((act_bwd_bias_kernel<V, A>), grid, dim3(256), 0, stream, m, n, g, ldg, h, ldh, gout, ldo, partial, \
+                       p.tpr, p.rows_per_block)
+    if (p.vec == 4) {
+        if (act == ACT_RELU) SPARC_ACT_LAUNCH(4, ACT_RELU); else SPARC_ACT_LAUNCH(4, ACT_TANH);
+    } else {
+        if (act == ACT_RELU) SPARC_ACT_LAUNCH(1, ACT_RELU); else SPARC_ACT_LAUNCH(1, ACT_TANH);
+    }
+#undef SPARC_ACT_LAUNCH
+    SPARC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(colsum_finish, dim3((n + 63) / 64), dim3(64 * COLSUM_LANES), 0, stream, p.nparts, n, partial, db);
+    SPARC_CHECK_LAUNCH();
+    return SPARC_OK;
+}
+
+extern "C" size_t sparc_wgrad_small_workspace_bytes(int n_out, int n_in) {
+    if (n_out <= 0 || n_out > SPARC_MAX_K || n_in <= 0) return 0;
+    const int pad = (n_out + 15) / 16 * 16;
+    return sparc_align_up((size_t)WGRAD_CHUNKS * pad * (size_t)n_in * sizeof(float)) + 256;
+}
+
+extern "C" int sparc_wgrad_small(int64_t m, int n_out, int n_in, const float* g, int64_t ldg, const float* h, int64_t ldh,
+                                 float* dW, void* ws, size_t ws_bytes, sparc_stream_t stream) {
+    if (m < 0 || n_out <= 0 || n_out > SPARC_MAX_K || n_in <= 0 || n_in % 64 != 0 || !g || !h || !dW || ldg < n_out ||
+        ldh < n_in || ldh % 4 != 0 || !aligned16(h))
+        return SPARC_ERR_ARG;
+    if (ws_bytes < sparc_wgrad_small_workspace_bytes(n_out, n_in) || !ws || (reinterpret_cast<uintptr_t>(ws) & 255)) return SPARC_ERR_WS;
+    if (m == 0) return hipMemsetAsync(dW, 0, (size_t)n_out * n_in * sizeof(float), stream) == hipSuccess ? SPARC_OK : SPARC_ERR_LAUNCH;
+    const int nt = (n_out + 15) / 16;
+    int64_t rpb = (m + WGRAD_CHUNKS - 1) / WGRAD_CHUNKS;
+    rpb = (rpb + 15) / 16 * 16;
+    const int nchunks = (int)((m + rpb - 1) / rpb);
+    float* partial = static_cast<float*>(ws);
+    dim3 grid(n_in / 64, nchunks);
+    const size_t lds = (size_t)4 * nt * 16 * 64 * sizeof(float);
+    switch (nt) {
+        case 1: hipLaunchKernelGGL((wgrad_small_kernel<1>), grid, dim3(256), lds, stream, m, n_out, n_in, g, ldg, h, ldh, partial, rpb); break;
+        case 2: hipLaunchKernelGGL((wgrad_small_kernel<2>), grid, dim3(256), lds, stream, m, n_out, n_in, g, ldg, h, ldh, partial, rpb); break;
+        case 3: hipLaunchKernelGGL((wgrad_small_kernel<3>), grid, dim3(256), lds, stream, m, n_out, n_in, g, ldg, h, ldh, partial, rpb); break;
+        default: hipLaunchKernelGGL((wgrad_small_kernel<4>), grid, dim3(256), lds, stream, m, n_out, n_in, g, ldg, h, ldh, partial, rpb); break;
+    }
+    SPARC_CHECK_LAUNCH();
+    const int64_t total = (int64_t)n_out * n_in;
+    hipLaunchKernelGGL(wgrad_finish, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, nchunks, n_out, nt * 16, n_in,
+                       partial, dW);
+    SPARC_CHECK_LAUNCH();
+    return SPARC_OK;
+}

@@ -41,6 +41,67 @@ def orth_apply(Yt: torch.Tensor, Wo: torch.Tensor, transpose: bool = False) -> t
     return Z
 
 
+ACT_RELU = 0
+ACT_TANH = 1
+
+
+def act_bwd_bias(g: torch.Tensor, h: torch.Tensor, act: int):
+    """(g * act'(h), column sums of it): the gradient entering a Linear layer and its bias gradient."""
+    m, n = h.shape
+    gout = torch.empty(m, n, dtype=torch.float32, device=h.device)
+    db = torch.empty(n, dtype=torch.float32, device=h.device)
+    nbytes = lib.sparc_act_bwd_bias_workspace_bytes(m, n)
+    ws = Workspace.get(nbytes, h.device)
+    with torch.cuda.device(h.device):
+        check(lib.sparc_act_bwd_bias(m, n, int(act), _ptr(g), g.stride(0), _ptr(h), h.stride(0), _ptr(gout), n, _ptr(db),
+                                     _ptr(ws), nbytes, _stream()), "sparc_act_bwd_bias")
+    return gout, db
+
+
+def wgrad_small(g: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
+    """g^T h for a narrow g [m, n_out <= 64] and h [m, n_in], n_in a multiple of 64."""
+    m, n_out = g.shape
+    n_in = h.shape[1]
+    dW = torch.empty(n_out, n_in, dtype=torch.float32, device=h.device)
+    nbytes = lib.sparc_wgrad_small_workspace_bytes(n_out, n_in)
+    ws = Workspace.get(nbytes, h.device)
+    with torch.cuda.device(h.device):
+        check(lib.sparc_wgrad_small(m, n_out, n_in, _ptr(g), g.stride(0), _ptr(h), h.stride(0), _ptr(dW), _ptr(ws), nbytes,
+                                    _stream()), "sparc_wgrad_small")
+    return dW
+
+
+class LinearAct(torch.autograd.Function):
+    """act(x W^T + b) of one MLP layer (src/SpectralTrainer.py:28-39): the products are library
+    GEMMs (bias and ReLU in the forward product's epilogue); the activation derivative, the bias
+    gradient and the narrow output layer's weight gradient run in libsparc_hip.so."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, act):
+        require_gpu(x.device)
+        if act == ACT_RELU:
+            h = torch._addmm_activation(b, x, W.t())
+        else:
+            h = torch.addmm(b, x, W.t()).tanh_()
+        ctx.save_for_backward(x, W, h)
+        ctx.act = act
+        return h
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W, h = ctx.saved_tensors
+        gp, db = act_bwd_bias(_f32c(g), h, ctx.act)
+        dx = gp.mm(W) if ctx.needs_input_grad[0] else None
+        dW = None
+        if ctx.needs_input_grad[1]:
+            n_out, n_in = W.shape
+            if n_out <= 64 and n_in % 64 == 0 and x.is_contiguous() and x.data_ptr() % 16 == 0:
+                dW = wgrad_small(gp, x)
+            else:
+                dW = gp.t().mm(x)
+        return dx, dW, (db if ctx.needs_input_grad[2] else None), None
+
+
 class OrthWeights(torch.autograd.Function):
     """Yt [m, k] -> orthonormalisation weights [k, k]  (src/SpectralTrainer.py:42-70)."""
 

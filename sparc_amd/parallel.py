@@ -88,7 +88,7 @@ class ShardedSpectralTrainer:
             for p in self.net.parameters():
                 broadcast(p.data, 0, group)
         self.grads = FlatGradients(list(self.net.parameters()))
-        self.optimizer = torch.optim.Adam(self.net.parameters(), lr=lr)
+        self.optimizer = torch.optim.Adam(self.net.parameters(), lr=lr, fused=True)
         self.criterion = SpectralNetLoss()
         self.features = []
         self.batches = []

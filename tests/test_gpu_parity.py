@@ -322,6 +322,49 @@ def test_orth_not_positive_definite_is_reported(dev):
     assert int(OrthWeights.last_info) != 0
 
 
+# ---------------------------------------------------------------- MLP backward helpers
+@pytest.mark.parametrize("m,n,act", [(1000, 1024, 0), (777, 47, 1), (5, 3, 0), (4097, 512, 0), (33, 2052, 1), (1, 1, 1)])
+def test_act_bwd_bias_matches_torch(dev, m, n, act):
+    from sparc_amd.ops import act_bwd_bias
+    gen = torch.Generator().manual_seed(m + n)
+    g = torch.randn(m, n, generator=gen)
+    pre = torch.randn(m, n, generator=gen)
+    h = torch.relu(pre) if act == 0 else torch.tanh(pre)
+    want = torch.where(h > 0, g, torch.zeros(())) if act == 0 else g * (1 - h * h)
+    gout, db = act_bwd_bias(g.to(dev), h.to(dev), act)
+    if act == 0:
+        assert torch.equal(gout.cpu(), want)  # a select: exact
+    else:
+        assert rel(gout.cpu().numpy(), want.numpy()) < 1e-6  # 1 - h*h may be contracted to an fma on the device
+    assert rel(db.cpu().numpy(), want.double().sum(0).numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("m,n_out,n_in", [(3001, 47, 512), (100, 16, 64), (3, 64, 128), (24491, 33, 512)])
+def test_wgrad_small_matches_float64(dev, m, n_out, n_in):
+    from sparc_amd.ops import wgrad_small
+    gen = torch.Generator().manual_seed(m)
+    g = torch.randn(m, n_out, generator=gen)
+    h = torch.randn(m, n_in, generator=gen)
+    dW = wgrad_small(g.to(dev), h.to(dev))
+    assert rel(dW.cpu().numpy(), (g.double().t() @ h.double()).numpy()) < 1e-5
+
+
+def test_linear_act_matches_torch_layers(dev):
+    from sparc_amd.ops import LinearAct
+    torch.manual_seed(3)
+    for (m, din, dout, act) in [(513, 10, 128, 0), (513, 128, 47, 1), (64, 7, 5, 0)]:
+        lin = torch.nn.Linear(din, dout).to(dev)
+        x = torch.randn(m, din, device=dev, requires_grad=True)
+        t = torch.randn(m, dout, device=dev)
+        ref = (torch.relu if act == 0 else torch.tanh)(lin(x))
+        rg = torch.autograd.grad((ref * t).sum(), [x, lin.weight, lin.bias])
+        out = LinearAct.apply(x, lin.weight, lin.bias, act)
+        og = torch.autograd.grad((out * t).sum(), [x, lin.weight, lin.bias])
+        assert rel(out.detach().cpu().numpy(), ref.detach().cpu().numpy()) < 1e-5
+        for a, b in zip(og, rg):
+            assert rel(a.cpu().numpy(), b.cpu().numpy()) < 1e-4
+
+
 # ---------------------------------------------------------------- one optimisation step
 def _load_model(g, prefix, din, k, dev):
     from sparc_amd.SpectralTrainer import SpectralNetModel
