@@ -66,6 +66,15 @@ class SpectralNetModel(nn.Module):
             self.orthonorm_weights = self._make_orthonorm_weights(Y_tilde, top_idx)
         return OrthApply.apply(Y_tilde, self.orthonorm_weights)
 
+    def forward_pair(self, x_orth: torch.Tensor, x_grad: torch.Tensor, top_idx=None) -> torch.Tensor:
+        """The two forwards of one training step (src/SpectralTrainer.py:222-223 then :232) as ONE pass
+        of the MLP over both batches: the parameters do not change between them, so the rows are the
+        same; the orthonormalisation weights come from x_orth's rows and are applied to x_grad's."""
+        m2 = x_orth.shape[0]
+        Y_tilde = self.embed_pre_orth(torch.cat([x_orth, x_grad], dim=0))
+        self.orthonorm_weights = self._make_orthonorm_weights(Y_tilde[:m2], top_idx)
+        return OrthApply.apply(Y_tilde[m2:], self.orthonorm_weights)
+
     def set_rotation_matrix(self, rotation_matrix):
         self.rotation_matrix = rotation_matrix
 
@@ -161,14 +170,11 @@ class SpectralTrainer:
                 np.random.permutation(len(feats[pid]))           # drawn as the reference does (:211), not applied
                 perm_2 = np.random.permutation(len(feats[pid_2]))  # (:218) only its head matters
 
-                # Orthogonality step (autograd stays on, as in the reference :222-223)
-                self.spectral_net.eval()
-                self.spectral_net(feats[pid_2], should_update_orth_weights=True, top_idx=perm_2[:k])
-
-                # Gradient step
+                # Orthogonality step (autograd stays on, as in the reference :222-223) and the
+                # forward of the gradient step (:232), one MLP pass over both batches
                 self.spectral_net.train()
                 self.optimizer.zero_grad()
-                Y = self.spectral_net(feats[pid], should_update_orth_weights=False)
+                Y = self.spectral_net.forward_pair(feats[pid_2], feats[pid], top_idx=perm_2[:k])
                 W = self._get_valid_affinity_matrix(sup[pid], feats[pid])
                 loss = self.criterion(W, Y, is_normalized=True)
                 loss.backward()

@@ -147,15 +147,14 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(int64_t m, int n_out, 
         for (int t = 0; t < 4; ++t) acc[a][t] = v4f{0.f, 0.f, 0.f, 0.f};
 
     const float* hp = h + (int64_t)blk * 64 + 4 * jj;
-#pragma unroll 2
-    for (int64_t rb = w0; rb < w1; rb += 4) {
-        const int64_t r = rb + kk;
-        const bool live = r < w1;
-        float4 hb = make_float4(0.f, 0.f, 0.f, 0.f);
-        float ga[NT];
-        if (live) hb = *reinterpret_cast<const float4*>(hp + r * ldh);
+    int gcol[NT];
+    bool gok[NT];
 #pragma unroll
-        for (int a = 0; a < NT; ++a) ga[a] = (live && 16 * a + jj < n_out) ? g[r * ldg + 16 * a + jj] : 0.f;
+    for (int a = 0; a < NT; ++a) {
+        gok[a] = 16 * a + jj < n_out;
+        gcol[a] = gok[a] ? 16 * a + jj : 0;
+    }
+    auto step = [&](const float4& hb, const float (&ga)[NT]) {
 #pragma unroll
         for (int a = 0; a < NT; ++a) {
             acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[a], hb.x, acc[a][0], 0, 0, 0);
@@ -163,6 +162,38 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(int64_t m, int n_out, 
             acc[a][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[a], hb.z, acc[a][2], 0, 0, 0);
             acc[a][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[a], hb.w, acc[a][3], 0, 0, 0);
         }
+    };
+    // whole groups of 16 rows: every load of the group is issued before its first product
+    int64_t rb = w0;
+    for (; rb + 16 <= w1; rb += 16) {
+        float4 hb[4];
+        float ga[4][NT];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t r = rb + 4 * u + kk;
+            hb[u] = *reinterpret_cast<const float4*>(hp + r * ldh);
+#pragma unroll
+            for (int a = 0; a < NT; ++a) ga[u][a] = g[r * ldg + gcol[a]];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int a = 0; a < NT; ++a) ga[u][a] = gok[a] ? ga[u][a] : 0.f;
+            step(hb[u], ga[u]);
+        }
+    }
+    for (; rb < w1; rb += 4) {  // the chunk's last rows
+        const int64_t r = rb + kk;
+        const bool live = r < w1;
+        const int64_t rc = live ? r : w1 - 1;
+        float4 hb = *reinterpret_cast<const float4*>(hp + rc * ldh);
+        float ga[NT];
+#pragma unroll
+        for (int a = 0; a < NT; ++a) ga[a] = g[rc * ldg + gcol[a]];
+        if (!live) hb = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int a = 0; a < NT; ++a) ga[a] = (live && gok[a]) ? ga[a] : 0.f;
+        step(hb, ga);
     }
 
     // the four waves' tiles meet in LDS and are added in wave order
@@ -202,7 +233,8 @@ __global__ __launch_bounds__(256) void wgrad_finish(int nchunks, int n_out, int 
     dW[e] = (s0 + s1) + (s2 + s3);
 }
 
-constexpr int WGRAD_CHUNKS = 32;
+constexpr int WGRAD_CHUNKS = 128;     // most row chunks of one product
+constexpr int WGRAD_CHUNK_ROWS = 256; // fewest rows of a chunk
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -253,7 +285,8 @@ extern "C" int sparc_wgrad_small(int64_t m, int n_out, int n_in, const float* g,
     if (m == 0) return hipMemsetAsync(dW, 0, (size_t)n_out * n_in * sizeof(float), stream) == hipSuccess ? SPARC_OK : SPARC_ERR_LAUNCH;
     const int nt = (n_out + 15) / 16;
     int64_t rpb = (m + WGRAD_CHUNKS - 1) / WGRAD_CHUNKS;
-    rpb = (rpb + 15) / 16 * 16;
+    if (rpb < WGRAD_CHUNK_ROWS) rpb = WGRAD_CHUNK_ROWS;
+    rpb = (rpb + 63) / 64 * 64;
     const int nchunks = (int)((m + rpb - 1) / rpb);
     float* partial = static_cast<float*>(ws);
     dim3 grid(n_in / 64, nchunks);

@@ -96,7 +96,9 @@ class LinearAct(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             n_out, n_in = W.shape
             if n_out <= 64 and n_in % 64 == 0 and x.is_contiguous() and x.data_ptr() % 16 == 0:
-                dW = wgrad_small(gp, x)
+                dW = wgrad_small(gp, x)           # narrow output layer
+            elif n_in <= 64 and n_out % 64 == 0:
+                dW = wgrad_small(x, gp).t()       # narrow input layer: (x^T gp)^T
             else:
                 dW = gp.t().mm(x)
         return dx, dW, (db if ctx.needs_input_grad[2] else None), None

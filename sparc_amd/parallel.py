@@ -102,11 +102,9 @@ class ShardedSpectralTrainer:
         """Orthogonality step on local batch pid_2, gradient step on local batch pid
         (src/SpectralTrainer.py:216-238), gradient averaged over the ranks before Adam."""
         net = self.net
-        net.eval()
-        net(self.features[pid_2], should_update_orth_weights=True, top_idx=top_idx)
         net.train()
         self.grads.zero()
-        Y = net(self.features[pid], should_update_orth_weights=False)
+        Y = net.forward_pair(self.features[pid_2], self.features[pid], top_idx=top_idx)
         loss = self.criterion(self.batches[pid], Y, is_normalized=True)
         loss.backward()
         self.grads.all_reduce_mean(self.group)

@@ -409,6 +409,24 @@ def test_train_step_matches_reference_golden(dev, golden):
     assert rel(vl.item(), g["val_loss"]) < TOL
 
 
+def test_forward_pair_equals_two_forwards(dev, golden):
+    """One MLP pass over both batches of a step gives the reference's two forwards and its gradients."""
+    from sparc_amd.SpectralTrainer import SpectralNetLoss
+    from sparc_amd.graph import ClusterBatch
+    g = golden("g5_step.npz")
+    x1, x2 = torch.tensor(g["x1"], device=dev), torch.tensor(g["x2"], device=dev)
+    batch = ClusterBatch.from_support(sup(g, "sup1_"), dev)
+    net = _load_model(g, "init.", 12, 8, dev)
+    Y = net.forward_pair(x2, x1, top_idx=g["perm2"][:8])
+    loss = SpectralNetLoss()(batch, Y, is_normalized=True)
+    loss.backward()
+    assert rel(net.orthonorm_weights.detach().cpu().numpy(), g["orth"]) < TOL
+    assert rel(Y.detach().cpu().numpy()[g["perm1"]], g["Y"]) < TOL
+    assert rel(loss.item(), g["loss"]) < TOL
+    for name, p in net.named_parameters():
+        assert rel(p.grad.cpu().numpy(), g["grad." + name]) < 5e-4, name
+
+
 def test_trainer_end_to_end_matches_reference(dev, golden, tmp_path, monkeypatch, capsys):
     """Two epochs of SpectralTrainer.train with the reference's seeds and data."""
     from sparc_amd.SpectralTrainer import SpectralTrainer

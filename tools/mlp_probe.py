@@ -59,3 +59,20 @@ for n, act in [(1024, 0), (512, 0), (47, 1)]:
 g = torch.randn(m, 47, device=dev)
 h = torch.randn(m, 512, device=dev)
 print(f"wgrad_small 47x512: {timeit(lambda: wgrad_small(g, h)):.1f} us", flush=True)
+
+# forward product with the weight stored transposed (NN instead of NT)
+for mm_ in (24500, 49000):
+    for (K, N) in [(1024, 1024), (1024, 512)]:
+        x = torch.randn(mm_, K, device=dev)
+        W = torch.randn(N, K, device=dev) / K ** 0.5
+        Wt = W.t().contiguous()
+        b = torch.randn(N, device=dev)
+        t_nt = timeit(lambda: torch._addmm_activation(b, x, W.t()))
+        t_nn = timeit(lambda: torch._addmm_activation(b, x, Wt))
+        g = torch.randn(mm_, N, device=dev)
+        t_dx = timeit(lambda: torch.mm(g, W))
+        t_dx_t = timeit(lambda: torch.mm(g, Wt.t()))
+        t_dw = timeit(lambda: torch.mm(g.t(), x))
+        t_dw2 = timeit(lambda: torch.mm(x.t(), g))
+        print(f"m={mm_} K={K} N={N}: fwd NT {t_nt:.1f} us, fwd NN {t_nn:.1f} us; dx {t_dx:.1f} / via Wt {t_dx_t:.1f}; "
+              f"dW g^T x {t_dw:.1f} / x^T g {t_dw2:.1f}", flush=True)
