@@ -36,10 +36,32 @@ class SpectralNet:
     def embed(self, X: torch.Tensor) -> np.ndarray:
         return np.array(X.detach().cpu())
 
-    def predict(self, X: torch.Tensor) -> np.ndarray:
-        """Embeddings with the orthonormalisation weights left by the last training step
-        (src/SpectralNet.py:80-98)."""
-        X = X.to(self.device)
+    def predict(self, X: torch.Tensor, chunk_rows: int = 1 << 18) -> np.ndarray:
+        """Embeddings of every row of X with the orthonormalisation weights left by the last
+        training step (src/SpectralNet.py:80-98).  The rows are independent, so a whole graph
+        (2.4 M nodes for Amazon2M) is pushed through in row chunks: X may stay on the host."""
+        n = int(X.shape[0])
+        k = int(self.spec_net.orthonorm_weights.shape[0])
+        out = np.empty((n, k), dtype=np.float32)
+        self.spec_net.eval()
         with torch.no_grad():
-            self.embeddings_ = self.spec_net(X, should_update_orth_weights=False).detach().cpu().numpy()
+            for a in range(0, n, chunk_rows):
+                x = X[a:a + chunk_rows].to(self.device, dtype=torch.float32)
+                out[a:a + chunk_rows] = self.spec_net(x, should_update_orth_weights=False).cpu().numpy()
+        self.embeddings_ = out
         return self.embeddings_
+
+
+def save_results(directory: str, Y: np.ndarray, X, labels, test_mask, val_mask, train_mask, X_embedded) -> None:
+    """The on-disk hand-over to the downstream SPARC models (src/main.py:134-153): seven .npy files,
+    `embeddings.npy` holding Y / sqrt(n)."""
+    import os
+    os.makedirs(directory, exist_ok=True)
+    Y = np.asarray(Y)
+    np.save(os.path.join(directory, "embeddings.npy"), Y / np.sqrt(Y.shape[0]))
+    np.save(os.path.join(directory, "features.npy"), X.cpu().numpy() if torch.is_tensor(X) else np.asarray(X))
+    np.save(os.path.join(directory, "labels.npy"), np.asarray(labels))
+    np.save(os.path.join(directory, "test_mask.npy"), np.asarray(test_mask))
+    np.save(os.path.join(directory, "val_mask.npy"), np.asarray(val_mask))
+    np.save(os.path.join(directory, "train_mask.npy"), np.asarray(train_mask))
+    np.save(os.path.join(directory, "X_embedded.npy"), np.asarray(X_embedded))

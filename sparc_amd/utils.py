@@ -107,15 +107,17 @@ def preprocess(adj, features, y_train, train_mask, visible_data, num_clusters, d
     """Per-partition batches for validation / test (src/utils.py:101-137).
 
     The reference obtains `parts` from METIS inside this function (partition_graph,
-    src/partition_utils.py:56); the partitioner is not part of this package, so the
-    parts are an argument (default: one part holding visible_data, the num_clusters == 1
-    case of the reference, :57-58)."""
+    src/partition_utils.py:56); here they come from the device partitioner
+    (sparc_amd.partition) unless the caller passes `parts` (e.g. a METIS result)."""
     device = device or _default_device()
     graph = _as_graph(adj, device)
     if parts is None:
-        if num_clusters != 1:
-            raise ValueError("pass `parts` (lists of node ids) when num_clusters > 1")
-        parts = [np.asarray(visible_data)]
+        visible = np.asarray(visible_data)
+        if num_clusters == 1:
+            parts = [visible]
+        else:
+            from .partition import partition_nodes
+            parts = partition_nodes(graph, visible, num_clusters)
     parts = [np.array(pt) for pt in parts]
     features_batches, support_batches, y_train_batches, train_mask_batches = [], [], [], []
     mode = MODE_ROWNORM if diag_lambda == -1 else MODE_ENHANCE

@@ -461,6 +461,25 @@ def test_trainer_end_to_end_matches_reference(dev, golden, tmp_path, monkeypatch
     assert (tmp_path / "weights" / "golden" / "spectralnet_weights.pth").exists()
 
 
+def test_predict_matches_reference_facade(dev, golden):
+    """SpectralNet.predict on all nodes with the reference's trained weights, pushed through in chunks."""
+    from sparc_amd.SpectralNet import SpectralNet
+    from sparc_amd.SpectralTrainer import SpectralNetModel
+    g = golden("g8_trainer.npz")
+    arch = {"n_layers": 4, "hidden_dim1": 32, "hidden_dim2": 32, "hidden_dim3": 16, "output_dim": 6}
+    net = SpectralNetModel(arch, 10, dev).to(dev)
+    net.load_state_dict({k[len("final."):]: torch.tensor(g[k]) for k in g.files if k.startswith("final.")})
+    net.orthonorm_weights = torch.tensor(g["final_orth"], device=dev)
+    facade = SpectralNet(n_clusters=6, config={"should_use_ae": False, "should_use_siamese": False})
+    facade.spec_net = net
+    X = torch.tensor(g["predict_X"])                      # stays on the host: predict moves chunks
+    Y = facade.predict(X, chunk_rows=100)
+    assert Y.dtype == np.float32 and Y.shape == g["predict_Y"].shape
+    assert rel(Y, g["predict_Y"]) < TOL
+    assert rel(Y, facade.predict(X)) < 1e-5               # chunking only changes the GEMM's rounding
+    assert facade.embeddings_ is Y or np.array_equal(facade.embeddings_, Y)
+
+
 # ---------------------------------------------------------------- support / degree construction
 def _csr(g, prefix):
     n = int(g["n"])
@@ -509,3 +528,34 @@ def test_device_degree_arrays_bit_exact(dev, golden):
     assert np.array_equal(rowsum.cpu().numpy(), g["rowsum_raw"])
     _, _, _, rowsum = graph.subblock(np.arange(n, dtype=np.int32), mode=2, binarize=False, diag_lambda=0.01)
     assert np.array_equal(rowsum.cpu().numpy(), g["rowsum_enh"])
+
+
+def test_preprocess_partitions_on_the_device(dev):
+    """preprocess with num_clusters > 1 and no parts given: the device partitioner supplies them."""
+    from sparc_amd.partition import edge_cut
+    from sparc_amd.utils import DeviceGraph, preprocess
+    rng = np.random.default_rng(11)
+    n, k = 2000, 8
+    lab = np.repeat(np.arange(k), n // k)
+    u = rng.integers(0, n, 20000)
+    v = np.where(rng.random(20000) < 0.85, lab[u] * (n // k) + rng.integers(0, n // k, 20000), rng.integers(0, n, 20000))
+    A = sp.coo_matrix((np.ones(len(u)), (u, v)), shape=(n, n))
+    A = sp.csr_matrix(((A + A.T + sp.eye(n)) > 0) * 1.0)
+    feats = rng.standard_normal((n, 5)).astype(np.float32)
+    y = np.zeros((n, 3), dtype=np.float32)
+    mask = np.ones(n, dtype=bool)
+    visible = rng.permutation(n)[:1800]           # a subset of the nodes, as the reference's train split
+    parts, fb, sb, yb, mb = preprocess(DeviceGraph.from_scipy(A, dev), feats, y, mask, visible, k)
+    assert len(parts) == k and sorted(np.concatenate(parts).tolist()) == sorted(visible.tolist())
+    assert max(len(p) for p in parts) <= int(np.ceil(1800 / k * 1.03)) + 1
+    where = np.full(n, -1)
+    for g_, p in enumerate(parts):
+        where[p] = g_
+    sub = sp.coo_matrix(A[visible][:, visible])
+    cut = int((where[visible[sub.row]] != where[visible[sub.col]]).sum()) // 2
+    planted_cut = int((lab[visible[sub.row]] != lab[visible[sub.col]]).sum()) // 2
+    assert cut <= 1.3 * planted_cut
+    for p, (coords, values, shape) in zip(parts, sb):   # supports are the oracle's for these parts
+        ref = O.as_support_tuple(O.row_normalize(sp.csr_matrix((A[p][:, p] > 0) * 1.0)))
+        ours = O.canonical_support((coords.cpu().numpy(), values.cpu().numpy(), shape))
+        assert np.array_equal(ours[0], O.canonical_support(ref)[0]) and np.array_equal(ours[1], O.canonical_support(ref)[1])

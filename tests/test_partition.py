@@ -1,0 +1,123 @@
+"""The balanced k-way partitioner that stands in for METIS (src/partition_utils.py:56) and the
+partition_graph wrapper around it (src/partition_utils.py:30-81).  METIS itself is absent, so its
+cut is parity-unpinned: these tests pin the contract (k parts, every node once, balance) and the
+quality on graphs with a known good cut; the post-partition construction (parts lists, intra-part
+adjacency) is compared with the oracle's restatement of the reference, which the golden vectors pin.
+The same torch code runs on the MI355X in production; here it runs on host tensors."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from oracle import sparc_oracle as O
+from sparc_amd.partition import edge_cut, kway_partition, partition_graph
+
+CPU = torch.device("cpu")
+
+
+def planted(n, k, n_edges, p_in, seed=0):
+    rng = np.random.default_rng(seed)
+    lab = np.repeat(np.arange(k), n // k)
+    u = rng.integers(0, n, n_edges)
+    same = rng.random(n_edges) < p_in
+    v = np.where(same, lab[u] * (n // k) + rng.integers(0, n // k, n_edges), rng.integers(0, n, n_edges))
+    keep = u != v
+    u, v = u[keep], v[keep]
+    key = np.unique(np.concatenate([u * n + v, v * n + u]))
+    return lab, torch.from_numpy(key // n), torch.from_numpy(key % n)
+
+
+def check_contract(part, n, k, imbalance=0.03):
+    assert part.shape == (n,) and part.dtype == torch.int64
+    sizes = torch.bincount(part, minlength=k)
+    assert sizes.numel() == k and int(sizes.sum()) == n
+    assert int(sizes.min()) > 0
+    cap = max(int(np.ceil(n / k * (1 + imbalance))), int(np.ceil(n / k)) + 1)
+    assert int(sizes.max()) <= cap
+    return sizes
+
+
+def test_recovers_well_separated_clusters_exactly():
+    n, k = 4000, 16
+    lab, src, dst = planted(n, k, 40000, 0.8)
+    part = kway_partition(n, src, dst, k)
+    check_contract(part, n, k)
+    assert edge_cut(part, src, dst) == edge_cut(torch.from_numpy(lab), src, dst)
+    # the same partition up to the numbering of the parts
+    pairs = np.unique(np.stack([lab, part.numpy()], axis=1), axis=0)
+    assert len(pairs) == k
+
+
+@pytest.mark.parametrize("n,k,e,p_in,slack", [(20000, 40, 250000, 0.7, 1.25), (4000, 16, 40000, 0.5, 1.6),
+                                                (3000, 100, 30000, 0.8, 1.3)])
+def test_cut_is_close_to_the_planted_cut(n, k, e, p_in, slack):
+    lab, src, dst = planted(n, k, e, p_in, seed=1)
+    part = kway_partition(n, src, dst, k)
+    check_contract(part, n, k)
+    assert edge_cut(part, src, dst) <= slack * edge_cut(torch.from_numpy(lab), src, dst)
+
+
+def test_deterministic():
+    lab, src, dst = planted(3000, 10, 30000, 0.6, seed=2)
+    a = kway_partition(3000, src, dst, 10)
+    b = kway_partition(3000, src, dst, 10)
+    assert torch.equal(a, b)
+
+
+def test_ring_of_cliques():
+    c, s = 12, 20   # 12 cliques of 20 nodes joined in a ring
+    rows, cols = [], []
+    for q in range(c):
+        for i in range(s):
+            for j in range(s):
+                if i != j:
+                    rows.append(q * s + i), cols.append(q * s + j)
+        a, b = q * s, ((q + 1) % c) * s + 1
+        rows += [a, b]
+        cols += [b, a]
+    src, dst = torch.tensor(rows), torch.tensor(cols)
+    part = kway_partition(c * s, src, dst, c, imbalance=0.0)
+    check_contract(part, c * s, c, 0.0)
+    assert edge_cut(part, src, dst) == c
+
+
+def test_degenerate_inputs():
+    e = torch.zeros(0, dtype=torch.int64)
+    assert kway_partition(5, e, e, 1).tolist() == [0] * 5
+    part = kway_partition(10, e, e, 3)             # no edges at all: still 3 balanced parts
+    check_contract(part, 10, 3)
+    with pytest.raises(ValueError):
+        kway_partition(3, e, e, 4)
+    src, dst = torch.tensor([0, 1]), torch.tensor([1, 0])   # one edge, many isolated nodes
+    check_contract(kway_partition(9, src, dst, 3), 9, 3)
+
+
+def test_partition_graph_wrapper_matches_reference_construction():
+    """With the groups given, parts and the intra-part adjacency are the reference's (oracle restatement)."""
+    rng = np.random.default_rng(5)
+    n = 60
+    A = sp.random(n, n, density=0.1, random_state=np.random.RandomState(5), format="csr")
+    A.data[:] = 1.0
+    A = sp.csr_matrix(((A + A.T + sp.eye(n)) > 0) * 1.0)
+    idx = np.arange(n)
+    groups = rng.integers(0, 4, n)
+    part_adj, parts = partition_graph(A, idx, 4, groups=groups)
+    ref_adj, ref_parts = O.intra_part_adjacency(A, idx, groups, 4)
+    assert (part_adj != ref_adj).nnz == 0 and part_adj.shape == ref_adj.shape
+    assert parts == ref_parts
+
+
+def test_partition_graph_native_on_host_tensors():
+    lab, src, dst = planted(800, 8, 8000, 0.85, seed=3)
+    A = sp.csr_matrix((np.ones(src.numel()), (src.numpy(), dst.numpy())), shape=(800, 800)) + sp.eye(800)
+    part_adj, parts = partition_graph(sp.csr_matrix(A), np.arange(800), 8, device=CPU)
+    assert sorted(x for p in parts for x in p) == list(range(800))
+    assert len(parts) == 8 and max(len(p) for p in parts) <= 104
+    # intra-part adjacency: no entry between different parts, diagonal kept
+    where = np.empty(800, dtype=np.int64)
+    for g, p in enumerate(parts):
+        where[p] = g
+    coo = part_adj.tocoo()
+    live = coo.data != 0
+    assert np.all(where[coo.row[live]] == where[coo.col[live]])
+    assert part_adj.diagonal().sum() == 800

@@ -268,6 +268,15 @@ def main():
     init = ref_st.SpectralNetModel(tiny_config(6)["spectral"]["architecture"], input_dim=din, device=torch.device("cpu"))
     for name, p in init.state_dict().items():
         g8["init." + name] = p.numpy().copy()
+    # the facade's predict on all nodes with the trained model (src/SpectralNet.py:80-98)
+    import SpectralNet as ref_sn
+    with contextlib.redirect_stdout(io.StringIO()):
+        facade = ref_sn.SpectralNet(n_clusters=6, config=tiny_config(6))
+    facade.device = torch.device("cpu")
+    facade.spec_net = net
+    Xall = torch.cat(feats_b + vf, dim=0)
+    g8["predict_X"] = Xall.numpy()
+    g8["predict_Y"] = facade.predict(Xall).copy()
     np.savez_compressed(os.path.join(OUT, "g8_trainer.npz"), **g8)
     print(buf.getvalue())
     print("golden vectors written to", OUT)
