@@ -1,7 +1,7 @@
 """SpectralNet facade with the reference's interface (src/SpectralNet.py:10-113) for the
-SpectralNet stage.  The autoencoder and Siamese pre-training stages of the reference are
-separate stages that are not part of this package: configs that ask for them are refused
-loudly rather than silently skipped."""
+SpectralNet stage and the autoencoder pre-embedding stage.  The Siamese stage (whose result the
+reference's SpectralTrainer never uses) is not part of this package: configs that ask for it are
+refused loudly rather than silently skipped."""
 from __future__ import annotations
 
 import numpy as np
@@ -23,9 +23,15 @@ class SpectralNet:
     def fit(self, train, val):
         """train = (parts, features_batches, support_batches, y_train_batches, train_mask_batches),
         val likewise (src/SpectralNet.py:25-58)."""
+        parts, features_batches, support_batches, y_train_batches, train_mask_batches = train
+        idx_parts, val_features_batches, val_support_batches, y_val_batches, val_mask_batches = val
         if self.config.get("should_use_ae", False):
-            raise NotImplementedError("the autoencoder pre-embedding stage (src/AETrainer.py) is not part of this package: "
-                                      "embed the features first and set should_use_ae to false")
+            from .AETrainer import AETrainer
+            ae_trainer = AETrainer(self.config, self.device)
+            self.ae_net = ae_trainer.train(features_batches, val_features_batches)
+            features_batches, val_features_batches = ae_trainer.embed(features_batches, val_features_batches)
+            train = parts, features_batches, support_batches, y_train_batches, train_mask_batches
+            val = idx_parts, val_features_batches, val_support_batches, y_val_batches, val_mask_batches
         if self.config.get("should_use_siamese", False):
             raise NotImplementedError("the Siamese stage is not part of this package (the reference's SpectralTrainer "
                                       "ignores its result, src/SpectralTrainer.py:144-167)")
@@ -34,7 +40,17 @@ class SpectralNet:
         self.spec_net = spectral_trainer.train(train, val)
 
     def embed(self, X: torch.Tensor) -> np.ndarray:
+        """The SpectralNet input of every row of X (src/SpectralNet.py:61-77): the autoencoder code
+        when the autoencoder stage is on, X itself otherwise."""
+        if self.config.get("should_use_ae", False):
+            X = self._encode_chunks(X)
         return np.array(X.detach().cpu())
+
+    def _encode_chunks(self, X: torch.Tensor, chunk_rows: int = 1 << 18) -> torch.Tensor:
+        self.ae_net.eval()
+        with torch.no_grad():
+            return torch.cat([self.ae_net.encode(X[a:a + chunk_rows].to(self.device, dtype=torch.float32)).cpu()
+                              for a in range(0, int(X.shape[0]), chunk_rows)], dim=0)
 
     def predict(self, X: torch.Tensor, chunk_rows: int = 1 << 18) -> np.ndarray:
         """Embeddings of every row of X with the orthonormalisation weights left by the last
@@ -47,6 +63,8 @@ class SpectralNet:
         with torch.no_grad():
             for a in range(0, n, chunk_rows):
                 x = X[a:a + chunk_rows].to(self.device, dtype=torch.float32)
+                if self.config.get("should_use_ae", False):
+                    x = self.ae_net.encode(x)
                 out[a:a + chunk_rows] = self.spec_net(x, should_update_orth_weights=False).cpu().numpy()
         self.embeddings_ = out
         return self.embeddings_

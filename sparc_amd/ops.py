@@ -43,6 +43,7 @@ def orth_apply(Yt: torch.Tensor, Wo: torch.Tensor, transpose: bool = False) -> t
 
 ACT_RELU = 0
 ACT_TANH = 1
+ACT_NONE = 2  # a Linear layer without activation (autoencoder bottleneck / output)
 
 
 def act_bwd_bias(g: torch.Tensor, h: torch.Tensor, act: int):
@@ -81,16 +82,22 @@ class LinearAct(torch.autograd.Function):
         require_gpu(x.device)
         if act == ACT_RELU:
             h = torch._addmm_activation(b, x, W.t())
-        else:
+        elif act == ACT_TANH:
             h = torch.addmm(b, x, W.t()).tanh_()
-        ctx.save_for_backward(x, W, h)
+        else:
+            h = torch.addmm(b, x, W.t())
+        ctx.save_for_backward(x, W, h if act != ACT_NONE else None)
         ctx.act = act
         return h
 
     @staticmethod
     def backward(ctx, g):
         x, W, h = ctx.saved_tensors
-        gp, db = act_bwd_bias(_f32c(g), h, ctx.act)
+        if ctx.act == ACT_NONE:
+            gp = _f32c(g)
+            db = gp.sum(0) if ctx.needs_input_grad[2] else None
+        else:
+            gp, db = act_bwd_bias(_f32c(g), h, ctx.act)
         dx = gp.mm(W) if ctx.needs_input_grad[0] else None
         dW = None
         if ctx.needs_input_grad[1]:

@@ -279,6 +279,33 @@ def main():
     g8["predict_Y"] = facade.predict(Xall).copy()
     np.savez_compressed(os.path.join(OUT, "g8_trainer.npz"), **g8)
     print(buf.getvalue())
+
+    # ---------------- G9: the autoencoder stage (src/AETrainer.py), 3 epochs ----------
+    import AETrainer as ref_ae
+    g9 = {}
+    rng = np.random.default_rng(44)
+    din9 = 20
+    fb = [torch.tensor(rng.standard_normal((70 + 9 * b, din9)), dtype=torch.float32) for b in range(3)]
+    vb = [torch.tensor(rng.standard_normal((40 + 5 * b, din9)), dtype=torch.float32) for b in range(2)]
+    cfg9 = {"dataset": "golden_ae", "ae": {"architecture": {"hidden_dim1": 24, "hidden_dim2": 24, "hidden_dim3": 12, "output_dim": 5},
+                                           "epochs": 3, "n_samples": 1000, "lr": 1e-3, "lr_decay": 0.1, "min_lr": 1e-7,
+                                           "patience": 10, "batch_size": 256}}
+    os.makedirs("weights/golden_ae", exist_ok=True)
+    torch.manual_seed(1)
+    buf9 = io.StringIO()
+    with contextlib.redirect_stdout(buf9):
+        tr9 = ref_ae.AETrainer(cfg9, torch.device("cpu"))
+        ae = tr9.train(fb, vb)
+        enc, enc_val = tr9.embed(fb, vb)
+    for b in range(3):
+        g9[f"feat{b}"], g9[f"enc{b}"] = fb[b].numpy(), enc[b].numpy()
+    for b in range(2):
+        g9[f"vfeat{b}"], g9[f"venc{b}"] = vb[b].numpy(), enc_val[b].numpy()
+    for name, p in ae.state_dict().items():
+        g9["final." + name] = p.numpy().copy()
+    g9["stdout"] = np.asarray(buf9.getvalue())
+    np.savez_compressed(os.path.join(OUT, "g9_ae.npz"), **g9)
+    print(buf9.getvalue())
     print("golden vectors written to", OUT)
     return 0
 
