@@ -22,7 +22,7 @@ import torch.nn as nn
 import torch.optim as optim
 
 from .graph import ClusterBatch, require_gpu
-from .ops import ACT_RELU, ACT_TANH, ORTH_CHOLESKY, ORTH_REFERENCE, LapLoss, LinearAct, OrthApply, OrthWeights
+from .ops import ACT_RELU, ACT_TANH, ORTH_CHOLESKY, ORTH_REFERENCE, LapLoss, LinearAct, OrthApply, OrthWeights, SplitRows
 
 
 class SpectralNetModel(nn.Module):
@@ -71,9 +71,9 @@ class SpectralNetModel(nn.Module):
         of the MLP over both batches: the parameters do not change between them, so the rows are the
         same; the orthonormalisation weights come from x_orth's rows and are applied to x_grad's."""
         m2 = x_orth.shape[0]
-        Y_tilde = self.embed_pre_orth(torch.cat([x_orth, x_grad], dim=0))
-        self.orthonorm_weights = self._make_orthonorm_weights(Y_tilde[:m2], top_idx)
-        return OrthApply.apply(Y_tilde[m2:], self.orthonorm_weights)
+        Yt_orth, Yt_grad = SplitRows.apply(self.embed_pre_orth(torch.cat([x_orth, x_grad], dim=0)), m2)
+        self.orthonorm_weights = self._make_orthonorm_weights(Yt_orth, top_idx)
+        return OrthApply.apply(Yt_grad, self.orthonorm_weights)
 
     def set_rotation_matrix(self, rotation_matrix):
         self.rotation_matrix = rotation_matrix

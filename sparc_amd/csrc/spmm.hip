@@ -626,8 +626,11 @@ int launch_tiled(const SpmmArgs& a, hipStream_t stream) {
     }
     {
         SpmmArgs b = a;
-        const char* dbg = getenv("SPARC_DBG");
-        b.dbg = dbg ? atoi(dbg) : 0;
+        static const int dbg = [] {  // developer switch for kernel ablation timings, read once
+            const char* e = getenv("SPARC_DBG");
+            return e ? atoi(e) : 0;
+        }();
+        b.dbg = dbg;
         Timed t(EPI, stream);
         hipLaunchKernelGGL((spmm_tiled<DUAL, EPI>), dim3(static_cast<unsigned>(a.ndesc)), dim3(TILED_THREADS), lds, stream, b);
     }

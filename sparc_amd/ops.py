@@ -111,6 +111,28 @@ class LinearAct(torch.autograd.Function):
         return dx, dW, (db if ctx.needs_input_grad[2] else None), None
 
 
+class SplitRows(torch.autograd.Function):
+    """(Y[:m2], Y[m2:]) as views; the backward concatenates the two gradients with one copy
+    instead of two zero-filled buffers and an add."""
+
+    @staticmethod
+    def forward(ctx, Y, m2):
+        ctx.m2 = m2
+        ctx.rows = Y.shape[0]
+        return Y[:m2], Y[m2:]
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        if g1 is None and g2 is None:
+            return None, None
+        ref = g1 if g1 is not None else g2
+        if g1 is None:
+            g1 = ref.new_zeros(ctx.m2, ref.shape[1])
+        if g2 is None:
+            g2 = ref.new_zeros(ctx.rows - ctx.m2, ref.shape[1])
+        return torch.cat([g1, g2], dim=0), None
+
+
 class OrthWeights(torch.autograd.Function):
     """Yt [m, k] -> orthonormalisation weights [k, k]  (src/SpectralTrainer.py:42-70)."""
 
