@@ -374,3 +374,25 @@ def orth_backward_operator(Yt2: np.ndarray, signs: np.ndarray, gWo: np.ndarray) 
     Gbar = Linv.T @ Phi @ Linv
     Gsym = 0.5 * (Gbar + Gbar.T)
     return Y64 @ (2.0 * Gsym)
+
+
+# --------------------------------------------------------------------------- token lists (consumer side)
+def spectral_token_lists(spectral_encoding: np.ndarray, features: np.ndarray, K: int) -> np.ndarray:
+    """Per-node token sequence of the downstream transformer models
+    (implementations/SPARCphormer/utils.py:268-298, same function in implementations/SAMBA/utils.py:239):
+    token 0 is the node's own feature row, token j+1 the mean feature row of its 2^(j+1) nearest
+    nodes in the spectral embedding (Euclidean, the node itself included), at most min(2^14, n)
+    neighbours; beyond the listed prefix lengths the mean runs over all of them."""
+    from sklearn.neighbors import NearestNeighbors
+    n = len(spectral_encoding)
+    knn = NearestNeighbors(n_neighbors=min(2 ** 14, n), algorithm="auto")
+    knn.fit(spectral_encoding)
+    _, indices = knn.kneighbors(spectral_encoding)
+    feats = np.asarray(features, dtype=np.float32)
+    out = np.empty((n, K + 1, feats.shape[1]), dtype=np.float32)
+    out[:, 0, :] = feats
+    starts = [1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768]
+    for j in range(K):
+        end = starts[j + 1] if j + 1 < len(starts) else indices.shape[1]
+        out[:, j + 1, :] = torch.mean(torch.from_numpy(feats)[torch.from_numpy(indices[:, :end])], dim=1).numpy()
+    return out

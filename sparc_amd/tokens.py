@@ -1,0 +1,48 @@
+"""Token lists for the downstream transformer models, built on the device from the spectral
+embedding (implementations/SPARCphormer/utils.py:268-298; the same function feeds SAMBA,
+implementations/SAMBA/utils.py:239): token 0 of a node is its own feature row, token j+1 the mean
+feature row of its 2^(j+1) nearest nodes in the embedding (the node itself included), out of at
+most min(2^14, n) neighbours.
+
+The reference asks scikit-learn for the 16 384 nearest neighbours of every node and then gathers
+and averages feature rows prefix by prefix.  Here a chunk of query rows gets its full distance
+row from one GEMM (||a||^2 + ||b||^2 - 2 a.b in float64), the prefix lengths become per-row
+distance thresholds (a k-th-smallest selection on the sorted row), and every prefix mean is a
+product of a 0/1 membership matrix with the feature matrix: K GEMMs per chunk instead of
+n x 16 384 row gathers.  Nodes at exactly equal distance on a prefix boundary (the reference
+breaks such ties by position) are all counted and the mean divides by the actual count.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .graph import require_gpu
+
+PREFIX = [1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768]
+MAX_NEIGHBOURS = 2 ** 14
+
+
+def spectral_token_lists(spectral_encoding, features, K: int, device=None, chunk_rows: int = 2048) -> torch.Tensor:
+    """float32 [n, K+1, F] on the host (as the reference returns it); inputs are numpy arrays or tensors."""
+    device = require_gpu(device or torch.device("cuda", torch.cuda.current_device()))
+    E = torch.as_tensor(np.asarray(spectral_encoding)).to(device=device, dtype=torch.float64)
+    Fm = torch.as_tensor(np.asarray(features)).to(device=device, dtype=torch.float32)
+    n, nf = Fm.shape
+    kmax = min(MAX_NEIGHBOURS, n)
+    ends = [min(PREFIX[j + 1] if j + 1 < len(PREFIX) else kmax, kmax) for j in range(K)]
+    out = torch.empty(n, K + 1, nf, dtype=torch.float32)
+    out[:, 0, :] = Fm.cpu()
+    sq = (E * E).sum(1)
+    for a in range(0, n, chunk_rows):
+        q = E[a:a + chunk_rows]
+        d2 = (sq[a:a + chunk_rows, None] + sq[None, :] - 2.0 * (q @ E.t())).clamp_(min=0.0)
+        rows = torch.arange(q.shape[0], device=device)
+        d2[rows, a + rows] = -1.0                       # a node is its own nearest neighbour
+        srt = torch.sort(d2, dim=1).values
+        tok = torch.empty(q.shape[0], K, nf, dtype=torch.float32, device=device)
+        for j, e in enumerate(ends):
+            member = (d2 <= srt[:, e - 1:e]).to(torch.float32)
+            tok[:, j, :] = (member @ Fm) / member.sum(1, keepdim=True)
+        out[a:a + chunk_rows, 1:, :] = tok.cpu()
+    return out

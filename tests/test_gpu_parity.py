@@ -599,3 +599,24 @@ def test_autoencoder_stage_matches_reference(dev, golden, tmp_path, monkeypatch,
     assert rel(tr.embed_single(fb[0]).cpu().numpy(), g["enc0"]) < 1e-3
     rec = ae(x)
     assert rec.shape == x.shape
+
+
+# ---------------------------------------------------------------- token lists of the downstream models
+def test_token_lists_match_reference_golden(dev, golden):
+    from sparc_amd.tokens import spectral_token_lists
+    g = golden("g10_tokens.npz")
+    t = spectral_token_lists(g["encoding"], g["features"], int(g["K"]), device=dev, chunk_rows=64)
+    assert t.shape == g["tokens"].shape and t.dtype == torch.float32 and t.device.type == "cpu"
+    assert np.abs(t.numpy() - g["tokens"]).max() < 1e-5
+
+
+def test_token_lists_match_oracle_larger(dev):
+    from sparc_amd.tokens import spectral_token_lists
+    rng = np.random.default_rng(8)
+    n, k, nf, K = 3000, 16, 24, 13          # prefixes run past n: the last tokens average every node
+    E = rng.standard_normal((n, k))
+    Fm = rng.standard_normal((n, nf)).astype(np.float32)
+    want = O.spectral_token_lists(E, Fm, K)
+    got = spectral_token_lists(E, Fm, K, device=dev, chunk_rows=1000).numpy()
+    assert np.abs(got - want).max() < 2e-5
+    assert np.allclose(got[:, -1, :], Fm.mean(0, keepdims=True), atol=1e-5)

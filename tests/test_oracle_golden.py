@@ -214,3 +214,11 @@ def test_degree_arrays_bit_exact(golden):
     g = golden("g1_support.npz")
     train_adj = _csr(g, "train_")
     assert np.array_equal(np.asarray(train_adj.sum(axis=1)).ravel(), g["rowsum_raw"])
+
+
+def test_token_lists_oracle_matches_reference(golden):
+    """The consumer-side token lists (implementations/SPARCphormer/utils.py:268-298)."""
+    g = golden("g10_tokens.npz")
+    t = O.spectral_token_lists(g["encoding"], g["features"], int(g["K"]))
+    assert t.shape == g["tokens"].shape and t.dtype == np.float32
+    assert np.abs(t - g["tokens"]).max() < 1e-6

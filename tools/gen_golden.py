@@ -306,6 +306,26 @@ def main():
     g9["stdout"] = np.asarray(buf9.getvalue())
     np.savez_compressed(os.path.join(OUT, "g9_ae.npz"), **g9)
     print(buf9.getvalue())
+
+    # ---------------- G10: token lists of the downstream models (implementations/SPARCphormer/utils.py) ----
+    # the module imports dgl (absent) at load time and never uses it on this path: stubbed like metis
+    import importlib.util
+    dgl = types.ModuleType("dgl")
+    dgl.DGLGraph = object
+    sys.modules.setdefault("dgl", dgl)
+    spec = importlib.util.spec_from_file_location("sparcphormer_utils", os.path.join(REF, "implementations", "SPARCphormer", "utils.py"))
+    ph = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ph)
+    rng = np.random.default_rng(55)
+    n10, K10 = 150, 9
+    enc10 = rng.standard_normal((n10, 5))
+    feat10 = rng.standard_normal((n10, 7)).astype(np.float32)
+    mask10 = np.ones(n10, dtype=bool)
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        tok = ph.re_features_spectral_diffusion_distance_avarage_seq_spectral_encoding_coldstart(
+            enc10, feat10, K10, mask10, mask10, mask10)
+    np.savez_compressed(os.path.join(OUT, "g10_tokens.npz"), encoding=enc10, features=feat10, K=np.asarray(K10),
+                        tokens=tok.numpy())
     print("golden vectors written to", OUT)
     return 0
 
