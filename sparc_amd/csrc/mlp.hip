@@ -221,16 +221,14 @@ __global__ __launch_bounds__(256) void wgrad_finish(int nchunks, int n_out, int 
     const int i = (int)(e / n_in), j = (int)(e % n_in);
     const int64_t stride = (int64_t)n_out_pad * n_in;
     const float* p = partial + (int64_t)i * n_in + j;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // eight loads in flight, fixed order
     int c = 0;
-    for (; c + 3 < nchunks; c += 4) {
-        s0 += p[c * stride];
-        s1 += p[(c + 1) * stride];
-        s2 += p[(c + 2) * stride];
-        s3 += p[(c + 3) * stride];
+    for (; c + 8 <= nchunks; c += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] += p[(c + u) * stride];
     }
-    for (; c < nchunks; ++c) s0 += p[c * stride];
-    dW[e] = (s0 + s1) + (s2 + s3);
+    for (; c < nchunks; ++c) t[0] += p[c * stride];
+    dW[e] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
 }
 
 constexpr int WGRAD_CHUNKS = 128;     // most row chunks of one product

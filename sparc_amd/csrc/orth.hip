@@ -28,16 +28,55 @@ __global__ __launch_bounds__(256) void gram_partial(int64_t m, int k, const floa
 #pragma unroll
         for (int b = 0; b < NT; ++b) acc[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
 
-    for (int64_t r0 = base + wave * 4; r0 < end; r0 += 16) {
-        const int64_t r = r0 + lk;
-        const bool live = r < end;
+    // every wave takes a contiguous quarter of the block's rows, 16 rows (four MFMA steps) at a time:
+    // the 8 NT loads of a group are issued before its first product
+    const int64_t per_wave = ((end - base + 3) / 4 + 3) / 4 * 4;
+    const int64_t w0 = base + wave * per_wave;
+    const int64_t w1 = min(end, w0 + per_wave);
+    int col[NT];
+    bool cok[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        cok[t] = t * 16 + li < k;
+        col[t] = cok[t] ? t * 16 + li : 0;
+    }
+    int64_t rb = w0;
+    for (; rb + 16 <= w1; rb += 16) {
+        float pf[4][NT], qf[4][NT];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t r = rb + 4 * u + lk;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                pf[u][t] = P[r * ldp + col[t]];
+                qf[u][t] = Q[r * ldq + col[t]];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            double pa[NT], qb[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                pa[t] = cok[t] ? static_cast<double>(pf[u][t]) : 0.0;
+                qb[t] = cok[t] ? static_cast<double>(qf[u][t]) : 0.0;
+            }
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[a], qb[b], acc[a][b], 0, 0, 0);
+        }
+    }
+    for (; rb < w1; rb += 4) {  // last rows of the wave's range
+        const int64_t r = rb + lk;
+        const bool live = r < w1;
+        const int64_t rc = live ? r : w1 - 1;
         double pa[NT], qb[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int cidx = t * 16 + li;
-            const bool ok = live && cidx < k;
-            pa[t] = ok ? static_cast<double>(P[r * ldp + cidx]) : 0.0;
-            qb[t] = ok ? static_cast<double>(Q[r * ldq + cidx]) : 0.0;
+            const bool ok = live && cok[t];
+            const float pv = P[rc * ldp + col[t]], qv = Q[rc * ldq + col[t]];
+            pa[t] = ok ? static_cast<double>(pv) : 0.0;
+            qb[t] = ok ? static_cast<double>(qv) : 0.0;
         }
 #pragma unroll
         for (int a = 0; a < NT; ++a)
@@ -69,16 +108,14 @@ __global__ __launch_bounds__(256) void gram_partial(int64_t m, int k, const floa
 __global__ void gram_reduce(int kk, int nparts, const double* __restrict__ slab, double* __restrict__ G) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= kk) return;
-    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;  // four independent chains, fixed order
+    double t[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // eight independent chains, fixed order
     int b = 0;
-    for (; b + 4 <= nparts; b += 4) {
-        t0 += slab[static_cast<int64_t>(b) * kk + e];
-        t1 += slab[static_cast<int64_t>(b + 1) * kk + e];
-        t2 += slab[static_cast<int64_t>(b + 2) * kk + e];
-        t3 += slab[static_cast<int64_t>(b + 3) * kk + e];
+    for (; b + 8 <= nparts; b += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] += slab[static_cast<int64_t>(b + u) * kk + e];
     }
-    for (; b < nparts; ++b) t0 += slab[static_cast<int64_t>(b) * kk + e];
-    G[e] = (t0 + t1) + (t2 + t3);
+    for (; b < nparts; ++b) t[0] += slab[static_cast<int64_t>(b) * kk + e];
+    G[e] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
 }
 
 constexpr int KLD = SPARC_MAX_K + 1;  // leading dimension of the k x k LDS images (bank-conflict free columns)

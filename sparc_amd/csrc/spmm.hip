@@ -502,6 +502,7 @@ __global__ __launch_bounds__(256) void lap_scale(int64_t m, int k, int64_t ldy, 
     const int64_t base = blockIdx.x * rows_per_block;
     const int64_t end = min(m, base + rows_per_block);
     float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
     for (int64_t r = base + rg; r < end; r += RG) {
         const float4 rc0 = *reinterpret_cast<const float4*>(rowc + r * SPARC_ROWC);
         const float4 rc1 = *reinterpret_cast<const float4*>(rowc + r * SPARC_ROWC + 4);
@@ -539,16 +540,14 @@ __global__ void lap_colsum_finish(int KP, int nparts, bool dual, const float* __
     const int q = threadIdx.x / KP, col = threadIdx.x % KP;
     const int ns = dual ? 6 : 3;
     if (q < ns) {
-        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;  // four independent chains, fixed order
+        double t[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // eight independent chains, fixed order
         int b = 0;
-        for (; b + 4 <= nparts; b += 4) {
-            t0 += colpart[(static_cast<int64_t>(b) * 6 + q) * KP + col];
-            t1 += colpart[(static_cast<int64_t>(b + 1) * 6 + q) * KP + col];
-            t2 += colpart[(static_cast<int64_t>(b + 2) * 6 + q) * KP + col];
-            t3 += colpart[(static_cast<int64_t>(b + 3) * 6 + q) * KP + col];
+        for (; b + 8 <= nparts; b += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] += colpart[(static_cast<int64_t>(b + u) * 6 + q) * KP + col];
         }
-        for (; b < nparts; ++b) t0 += colpart[(static_cast<int64_t>(b) * 6 + q) * KP + col];
-        S[q][col] = (t0 + t1) + (t2 + t3);
+        for (; b < nparts; ++b) t[0] += colpart[(static_cast<int64_t>(b) * 6 + q) * KP + col];
+        S[q][col] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
     }
     __syncthreads();
     if (q < ns) {
@@ -740,7 +739,7 @@ extern "C" int sparc_spmm(int64_t m, int64_t nnz, const int64_t* rowptr, const i
 }
 
 namespace {
-constexpr int SCALE_MAX_BLOCKS = 128;
+constexpr int SCALE_MAX_BLOCKS = 256;
 struct LapPlan {
     int kp, W;
     int64_t nscale, rows_per_block, nloss;
