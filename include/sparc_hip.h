@@ -170,13 +170,21 @@ int sparc_orth_weights_bwd(int64_t m, int k, const double* gWo, const double* Rc
  *                     in one pass over g and h; all three [m][ld*], gout may alias g.
  * sparc_wgrad_small:  dW = g^T h, g [m][n_out] with n_out <= SPARC_MAX_K, h [m][n_in] with
  *                     n_in a multiple of 64 and 16-byte aligned rows: the weight gradient of the
- *                     output layer (f32 MFMA, fixed summation order). */
+ *                     output layer (f32 MFMA, fixed summation order).
+ * sparc_first_layer_bwd: the whole backward of the first Linear+ReLU layer (its input needs no
+ *                     gradient) in one pass over g and h [m][n], n a multiple of 64, 16-byte aligned
+ *                     rows: with gp = g * [h > 0] (never written out), dWt_db [din+1][n] receives
+ *                     x^T gp (the transposed weight gradient, x [m][din], din < SPARC_MAX_K) in rows
+ *                     0..din-1 and the bias gradient, the column sums of gp, in row din. */
 size_t sparc_act_bwd_bias_workspace_bytes(int64_t m, int n);
 int sparc_act_bwd_bias(int64_t m, int n, int act, const float* g, int64_t ldg, const float* h, int64_t ldh,
                        float* gout, int64_t ldo, float* db, void* ws, size_t ws_bytes, sparc_stream_t stream);
 size_t sparc_wgrad_small_workspace_bytes(int n_out, int n_in);
 int sparc_wgrad_small(int64_t m, int n_out, int n_in, const float* g, int64_t ldg, const float* h, int64_t ldh,
                       float* dW, void* ws, size_t ws_bytes, sparc_stream_t stream);
+size_t sparc_first_layer_bwd_workspace_bytes(int din, int n);
+int sparc_first_layer_bwd(int64_t m, int din, int n, const float* x, int64_t ldx, const float* g, int64_t ldg,
+                          const float* h, int64_t ldh, float* dWt_db, void* ws, size_t ws_bytes, sparc_stream_t stream);
 
 /* ---- support / degree construction -----------------------------------------------------------
  * Replaces the sparse algebra of preprocess_multicluster / preprocess (src/utils.py:60-137):

@@ -126,9 +126,15 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // Lane l = (jj = l & 15, kk = l >> 4).  Per step of four rows the lane reads h[row kk][4 jj .. 4 jj + 3]
 // (16 bytes) and g[row kk][16 it + jj]; product tile (it, t) therefore holds the OUTPUT columns
 // 4 j + t, j = 0..15, of the block: register r of lane l is dW[16 it + 4 kk + r][64 blk + 4 jj + t].
-template <int NT>
+//
+// FIRST (the backward of the MLP's first layer, whose input needs no gradient): the wide operand is
+// formed on the fly as h * [hmask > 0] (incoming gradient times the ReLU derivative, never written
+// out) and the narrow operand gets one more column of ones, so that row n_out of the result is the
+// column sum of the masked operand: the bias gradient.
+template <int NT, bool FIRST>
 __global__ __launch_bounds__(256) void wgrad_small_kernel(int64_t m, int n_out, int n_in, const float* __restrict__ g,
                                                           int64_t ldg, const float* __restrict__ h, int64_t ldh,
+                                                          const float* __restrict__ hmask, int64_t ldm,
                                                           float* __restrict__ partial, int64_t rows_per_block) {
     extern __shared__ float sm[];  // [4 waves][NT * 16][64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -147,13 +153,22 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(int64_t m, int n_out, 
         for (int t = 0; t < 4; ++t) acc[a][t] = v4f{0.f, 0.f, 0.f, 0.f};
 
     const float* hp = h + (int64_t)blk * 64 + 4 * jj;
+    const float* mp = FIRST ? hmask + (int64_t)blk * 64 + 4 * jj : nullptr;
     int gcol[NT];
-    bool gok[NT];
+    bool gok[NT], gone[NT];
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
         gok[a] = 16 * a + jj < n_out;
+        gone[a] = FIRST && 16 * a + jj == n_out;   // the column of ones
         gcol[a] = gok[a] ? 16 * a + jj : 0;
     }
+    auto masked = [](float4 v, const float4 mk) {
+        v.x = mk.x > 0.f ? v.x : 0.f;
+        v.y = mk.y > 0.f ? v.y : 0.f;
+        v.z = mk.z > 0.f ? v.z : 0.f;
+        v.w = mk.w > 0.f ? v.w : 0.f;
+        return v;
+    };
     auto step = [&](const float4& hb, const float (&ga)[NT]) {
 #pragma unroll
         for (int a = 0; a < NT; ++a) {
@@ -166,19 +181,21 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(int64_t m, int n_out, 
     // whole groups of 16 rows: every load of the group is issued before its first product
     int64_t rb = w0;
     for (; rb + 16 <= w1; rb += 16) {
-        float4 hb[4];
+        float4 hb[4], hm[4];
         float ga[4][NT];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int64_t r = rb + 4 * u + kk;
             hb[u] = *reinterpret_cast<const float4*>(hp + r * ldh);
+            if (FIRST) hm[u] = *reinterpret_cast<const float4*>(mp + r * ldm);
 #pragma unroll
             for (int a = 0; a < NT; ++a) ga[u][a] = g[r * ldg + gcol[a]];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
 #pragma unroll
-            for (int a = 0; a < NT; ++a) ga[u][a] = gok[a] ? ga[u][a] : 0.f;
+            for (int a = 0; a < NT; ++a) ga[u][a] = gok[a] ? ga[u][a] : (gone[a] ? 1.f : 0.f);
+            if (FIRST) hb[u] = masked(hb[u], hm[u]);
             step(hb[u], ga[u]);
         }
     }
@@ -187,12 +204,13 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(int64_t m, int n_out, 
         const bool live = r < w1;
         const int64_t rc = live ? r : w1 - 1;
         float4 hb = *reinterpret_cast<const float4*>(hp + rc * ldh);
+        if (FIRST) hb = masked(hb, *reinterpret_cast<const float4*>(mp + rc * ldm));
         float ga[NT];
 #pragma unroll
         for (int a = 0; a < NT; ++a) ga[a] = g[rc * ldg + gcol[a]];
         if (!live) hb = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int a = 0; a < NT; ++a) ga[a] = (live && gok[a]) ? ga[a] : 0.f;
+        for (int a = 0; a < NT; ++a) ga[a] = !live ? 0.f : (gok[a] ? ga[a] : (gone[a] ? 1.f : 0.f));
         step(hb, ga);
     }
 
@@ -274,14 +292,10 @@ extern "C" size_t sparc_wgrad_small_workspace_bytes(int n_out, int n_in) {
     return sparc_align_up((size_t)WGRAD_CHUNKS * pad * (size_t)n_in * sizeof(float)) + 256;
 }
 
-extern "C" int sparc_wgrad_small(int64_t m, int n_out, int n_in, const float* g, int64_t ldg, const float* h, int64_t ldh,
-                                 float* dW, void* ws, size_t ws_bytes, sparc_stream_t stream) {
-    if (m < 0 || n_out <= 0 || n_out > SPARC_MAX_K || n_in <= 0 || n_in % 64 != 0 || !g || !h || !dW || ldg < n_out ||
-        ldh < n_in || ldh % 4 != 0 || !aligned16(h))
-        return SPARC_ERR_ARG;
-    if (ws_bytes < sparc_wgrad_small_workspace_bytes(n_out, n_in) || !ws || (reinterpret_cast<uintptr_t>(ws) & 255)) return SPARC_ERR_WS;
-    if (m == 0) return hipMemsetAsync(dW, 0, (size_t)n_out * n_in * sizeof(float), stream) == hipSuccess ? SPARC_OK : SPARC_ERR_LAUNCH;
-    const int nt = (n_out + 15) / 16;
+namespace {
+int wgrad_launch(bool first, int64_t m, int n_out, int n_rows_out, int n_in, const float* g, int64_t ldg, const float* h,
+                 int64_t ldh, const float* hmask, int64_t ldm, float* dW, void* ws, sparc_stream_t stream) {
+    const int nt = (n_rows_out + 15) / 16;
     int64_t rpb = (m + WGRAD_CHUNKS - 1) / WGRAD_CHUNKS;
     if (rpb < WGRAD_CHUNK_ROWS) rpb = WGRAD_CHUNK_ROWS;
     rpb = (rpb + 63) / 64 * 64;
@@ -289,16 +303,56 @@ extern "C" int sparc_wgrad_small(int64_t m, int n_out, int n_in, const float* g,
     float* partial = static_cast<float*>(ws);
     dim3 grid(n_in / 64, nchunks);
     const size_t lds = (size_t)4 * nt * 16 * 64 * sizeof(float);
-    switch (nt) {
-        case 1: hipLaunchKernelGGL((wgrad_small_kernel<1>), grid, dim3(256), lds, stream, m, n_out, n_in, g, ldg, h, ldh, partial, rpb); break;
-        case 2: hipLaunchKernelGGL((wgrad_small_kernel<2>), grid, dim3(256), lds, stream, m, n_out, n_in, g, ldg, h, ldh, partial, rpb); break;
-        case 3: hipLaunchKernelGGL((wgrad_small_kernel<3>), grid, dim3(256), lds, stream, m, n_out, n_in, g, ldg, h, ldh, partial, rpb); break;
-        default: hipLaunchKernelGGL((wgrad_small_kernel<4>), grid, dim3(256), lds, stream, m, n_out, n_in, g, ldg, h, ldh, partial, rpb); break;
+#define SPARC_WGRAD(NT_, F_)                                                                                              \
+    hipLaunchKernelGGL((wgrad_small_kernel<NT_, F_>), grid, dim3(256), lds, stream, m, n_out, n_in, g, ldg, h, ldh, hmask, \
+                       ldm, partial, rpb)
+    if (first) {
+        switch (nt) {
+            case 1: SPARC_WGRAD(1, true); break;
+            case 2: SPARC_WGRAD(2, true); break;
+            case 3: SPARC_WGRAD(3, true); break;
+            default: SPARC_WGRAD(4, true); break;
+        }
+    } else {
+        switch (nt) {
+            case 1: SPARC_WGRAD(1, false); break;
+            case 2: SPARC_WGRAD(2, false); break;
+            case 3: SPARC_WGRAD(3, false); break;
+            default: SPARC_WGRAD(4, false); break;
+        }
     }
+#undef SPARC_WGRAD
     SPARC_CHECK_LAUNCH();
-    const int64_t total = (int64_t)n_out * n_in;
-    hipLaunchKernelGGL(wgrad_finish, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, nchunks, n_out, nt * 16, n_in,
-                       partial, dW);
+    const int64_t total = (int64_t)n_rows_out * n_in;
+    hipLaunchKernelGGL(wgrad_finish, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, nchunks, n_rows_out, nt * 16,
+                       n_in, partial, dW);
     SPARC_CHECK_LAUNCH();
     return SPARC_OK;
+}
+}  // namespace
+
+extern "C" int sparc_wgrad_small(int64_t m, int n_out, int n_in, const float* g, int64_t ldg, const float* h, int64_t ldh,
+                                 float* dW, void* ws, size_t ws_bytes, sparc_stream_t stream) {
+    if (m < 0 || n_out <= 0 || n_out > SPARC_MAX_K || n_in <= 0 || n_in % 64 != 0 || !g || !h || !dW || ldg < n_out ||
+        ldh < n_in || ldh % 4 != 0 || !aligned16(h))
+        return SPARC_ERR_ARG;
+    if (ws_bytes < sparc_wgrad_small_workspace_bytes(n_out, n_in) || !ws || (reinterpret_cast<uintptr_t>(ws) & 255)) return SPARC_ERR_WS;
+    if (m == 0) return hipMemsetAsync(dW, 0, (size_t)n_out * n_in * sizeof(float), stream) == hipSuccess ? SPARC_OK : SPARC_ERR_LAUNCH;
+    return wgrad_launch(false, m, n_out, n_out, n_in, g, ldg, h, ldh, nullptr, 0, dW, ws, stream);
+}
+
+extern "C" size_t sparc_first_layer_bwd_workspace_bytes(int din, int n) {
+    return sparc_wgrad_small_workspace_bytes(din + 1, n);
+}
+
+extern "C" int sparc_first_layer_bwd(int64_t m, int din, int n, const float* x, int64_t ldx, const float* g, int64_t ldg,
+                                     const float* h, int64_t ldh, float* dWt_db, void* ws, size_t ws_bytes,
+                                     sparc_stream_t stream) {
+    if (m < 0 || din <= 0 || din + 1 > SPARC_MAX_K || n <= 0 || n % 64 != 0 || !x || !g || !h || !dWt_db || ldx < din ||
+        ldg < n || ldh < n || ldg % 4 != 0 || ldh % 4 != 0 || !aligned16(g) || !aligned16(h))
+        return SPARC_ERR_ARG;
+    if (ws_bytes < sparc_first_layer_bwd_workspace_bytes(din, n) || !ws || (reinterpret_cast<uintptr_t>(ws) & 255)) return SPARC_ERR_WS;
+    if (m == 0)
+        return hipMemsetAsync(dWt_db, 0, (size_t)(din + 1) * n * sizeof(float), stream) == hipSuccess ? SPARC_OK : SPARC_ERR_LAUNCH;
+    return wgrad_launch(true, m, din, din + 1, n, x, ldx, g, ldg, h, ldh, dWt_db, ws, stream);
 }

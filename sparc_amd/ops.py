@@ -72,6 +72,20 @@ def wgrad_small(g: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
     return dW
 
 
+def first_layer_bwd(x: torch.Tensor, g: torch.Tensor, h: torch.Tensor):
+    """(dW [n, din] as a transposed view, db [n]) of a Linear+ReLU layer whose input needs no gradient,
+    in one pass over g and h: the masked gradient is never written out."""
+    m, din = x.shape
+    n = h.shape[1]
+    out = torch.empty(din + 1, n, dtype=torch.float32, device=h.device)
+    nbytes = lib.sparc_first_layer_bwd_workspace_bytes(din, n)
+    ws = Workspace.get(nbytes, h.device)
+    with torch.cuda.device(h.device):
+        check(lib.sparc_first_layer_bwd(m, din, n, _ptr(x), x.stride(0), _ptr(g), g.stride(0), _ptr(h), h.stride(0), _ptr(out),
+                                        _ptr(ws), nbytes, _stream()), "sparc_first_layer_bwd")
+    return out[:din].t(), out[din]
+
+
 class LinearAct(torch.autograd.Function):
     """act(x W^T + b) of one MLP layer (src/SpectralTrainer.py:28-39): the products are library
     GEMMs (bias and ReLU in the forward product's epilogue); the activation derivative, the bias
@@ -93,6 +107,12 @@ class LinearAct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, W, h = ctx.saved_tensors
+        if (ctx.act == ACT_RELU and not ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and x.shape[1] < 64
+                and W.shape[0] % 64 == 0 and x.dtype == torch.float32 and x.stride(1) == 1):
+            g = _f32c(g)
+            if g.data_ptr() % 16 == 0 and h.data_ptr() % 16 == 0:
+                dW, db = first_layer_bwd(x, g, h)
+                return None, dW, (db if ctx.needs_input_grad[2] else None), None
         if ctx.act == ACT_NONE:
             gp = _f32c(g)
             db = gp.sum(0) if ctx.needs_input_grad[2] else None

@@ -349,6 +349,33 @@ def test_wgrad_small_matches_float64(dev, m, n_out, n_in):
     assert rel(dW.cpu().numpy(), (g.double().t() @ h.double()).numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("m,din,n", [(3001, 10, 1024), (70, 63, 64), (5, 1, 128), (24491, 10, 256)])
+def test_first_layer_backward_matches_float64(dev, m, din, n):
+    from sparc_amd.ops import first_layer_bwd
+    gen = torch.Generator().manual_seed(m + din)
+    x = torch.randn(m, din, generator=gen)
+    g = torch.randn(m, n, generator=gen)
+    h = torch.relu(torch.randn(m, n, generator=gen))
+    gp = torch.where(h > 0, g, torch.zeros(())).double()
+    dW, db = first_layer_bwd(x.to(dev), g.to(dev), h.to(dev))
+    assert dW.shape == (n, din) and db.shape == (n,)
+    assert rel(dW.cpu().numpy(), (gp.t() @ x.double()).numpy()) < 1e-5
+    assert rel(db.cpu().numpy(), gp.sum(0).numpy()) < 1e-5
+
+
+def test_linear_act_first_layer_path(dev):
+    """A Linear+ReLU layer on an input that needs no gradient takes the one-pass backward."""
+    from sparc_amd.ops import LinearAct
+    torch.manual_seed(4)
+    lin = torch.nn.Linear(10, 128).to(dev)
+    x = torch.randn(777, 10, device=dev)
+    t = torch.randn(777, 128, device=dev)
+    rg = torch.autograd.grad((torch.relu(lin(x)) * t).sum(), [lin.weight, lin.bias])
+    og = torch.autograd.grad((LinearAct.apply(x, lin.weight, lin.bias, 0) * t).sum(), [lin.weight, lin.bias])
+    for a, b in zip(og, rg):
+        assert rel(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+
+
 def test_linear_act_matches_torch_layers(dev):
     from sparc_amd.ops import LinearAct
     torch.manual_seed(3)
