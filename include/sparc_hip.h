@@ -161,10 +161,10 @@ int sparc_orth_weights_bwd(int64_t m, int k, const double* gWo, const double* Rc
                            const double* Rinv, const double* signs, int mode, float* H,
                            sparc_stream_t stream);
 
-/* ---- MLP backward helpers ------------------------------------------------------------------------
+/* ---- MLP helpers ---------------------------------------------------------------------------------
  * The SpectralNet MLP is Linear+ReLU x3, Linear+Tanh (src/SpectralTrainer.py:28-39); its wide
- * products are library GEMMs.  These two replace the elementwise and narrow parts of the autograd
- * backward (src/SpectralTrainer.py:237):
+ * products are library GEMMs.  These replace the narrow products of the forward (:96-97) and the
+ * elementwise and narrow parts of the autograd backward (src/SpectralTrainer.py:237):
  * sparc_act_bwd_bias: gout = g * act'(h) with h the layer's OUTPUT (act 0: ReLU, h > 0 ? g : 0;
  *                     act 1: Tanh, g (1 - h^2)) and db[n] = column sums of gout (the bias gradient),
  *                     in one pass over g and h; all three [m][ld*], gout may alias g.
@@ -175,7 +175,15 @@ int sparc_orth_weights_bwd(int64_t m, int k, const double* gWo, const double* Rc
  *                     gradient) in one pass over g and h [m][n], n a multiple of 64, 16-byte aligned
  *                     rows: with gp = g * [h > 0] (never written out), dWt_db [din+1][n] receives
  *                     x^T gp (the transposed weight gradient, x [m][din], din < SPARC_MAX_K) in rows
- *                     0..din-1 and the bias gradient, the column sums of gp, in row din. */
+ *                     0..din-1 and the bias gradient, the column sums of gp, in row din.
+ * sparc_linear_narrow_fwd: out = act(x W^T + b) for the narrow output layer: x [m][K], K a multiple of
+ *                     16 with 16-byte aligned rows, W [n_out][K], n_out <= SPARC_MAX_K and
+ *                     16 (n_out rounded up to 16) (K + 4) floats within 150 KB of LDS; act 0 ReLU,
+ *                     1 Tanh, 2 none (f32 MFMA, x read once).
+ * sparc_dgrad_narrow_relu: dx = (g W) * [hprev > 0] and db_prev = column sums of dx: the input
+ *                     gradient of the narrow output layer (g [m][n_out], W [n_out][N], N a multiple
+ *                     of 64) fused with the ReLU derivative and the bias gradient of the layer
+ *                     before it, whose output hprev [m][N] is this layer's input. */
 size_t sparc_act_bwd_bias_workspace_bytes(int64_t m, int n);
 int sparc_act_bwd_bias(int64_t m, int n, int act, const float* g, int64_t ldg, const float* h, int64_t ldh,
                        float* gout, int64_t ldo, float* db, void* ws, size_t ws_bytes, sparc_stream_t stream);
@@ -185,6 +193,12 @@ int sparc_wgrad_small(int64_t m, int n_out, int n_in, const float* g, int64_t ld
 size_t sparc_first_layer_bwd_workspace_bytes(int din, int n);
 int sparc_first_layer_bwd(int64_t m, int din, int n, const float* x, int64_t ldx, const float* g, int64_t ldg,
                           const float* h, int64_t ldh, float* dWt_db, void* ws, size_t ws_bytes, sparc_stream_t stream);
+int sparc_linear_narrow_fwd(int64_t m, int K, int n_out, int act, const float* x, int64_t ldx, const float* W,
+                            const float* b, float* out, int64_t ldo, sparc_stream_t stream);
+size_t sparc_dgrad_narrow_relu_workspace_bytes(int64_t m, int N);
+int sparc_dgrad_narrow_relu(int64_t m, int n_out, int N, const float* g, int64_t ldg, const float* W,
+                            const float* hprev, int64_t ldh, float* dx, int64_t ldx, float* db_prev,
+                            void* ws, size_t ws_bytes, sparc_stream_t stream);
 
 /* ---- support / degree construction -----------------------------------------------------------
  * Replaces the sparse algebra of preprocess_multicluster / preprocess (src/utils.py:60-137):

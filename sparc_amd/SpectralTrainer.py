@@ -22,7 +22,7 @@ import torch.nn as nn
 import torch.optim as optim
 
 from .graph import ClusterBatch, require_gpu
-from .ops import ACT_RELU, ACT_TANH, ORTH_CHOLESKY, ORTH_REFERENCE, LapLoss, LinearAct, OrthApply, OrthWeights, SplitRows
+from .ops import ACT_RELU, ACT_TANH, ORTH_CHOLESKY, ORTH_REFERENCE, LapLoss, LinearAct, OrthApply, OrthWeights, SpectralMLP, SplitRows
 
 
 class SpectralNetModel(nn.Module):
@@ -55,9 +55,12 @@ class SpectralNetModel(nn.Module):
         return OrthWeights.apply(Y, top_idx, self.orth_mode)
 
     def embed_pre_orth(self, x: torch.Tensor) -> torch.Tensor:
-        for layer in self.layers:
-            lin, act = layer[0], layer[1]
-            x = LinearAct.apply(x, lin.weight, lin.bias, ACT_TANH if isinstance(act, nn.Tanh) else ACT_RELU)
+        kinds = [isinstance(layer[1], nn.Tanh) for layer in self.layers]
+        if kinds[-1] and not any(kinds[:-1]) and x.dtype == torch.float32:   # ReLU ... ReLU, Tanh: the fused MLP
+            params = [p for layer in self.layers for p in (layer[0].weight, layer[0].bias)]
+            return SpectralMLP.apply(x.contiguous(), *params)
+        for layer, is_tanh in zip(self.layers, kinds):
+            x = LinearAct.apply(x, layer[0].weight, layer[0].bias, ACT_TANH if is_tanh else ACT_RELU)
         return x
 
     def forward(self, x: torch.Tensor, should_update_orth_weights: bool = True, top_idx=None) -> torch.Tensor:

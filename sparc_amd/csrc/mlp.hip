@@ -249,6 +249,151 @@ __global__ __launch_bounds__(256) void wgrad_finish(int nchunks, int n_out, int 
     dW[e] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
 }
 
+// out = act(x W^T + b) for a narrow output (n_out <= 64): the MLP's last layer.  W (n_out x K, zero
+// padded to NT * 16 rows) sits in LDS with a 4-float row pad; a wave produces 16 rows at a time.
+// Lane l = (i = l & 15, kk = l >> 4) reads x[row i][16 t + 4 kk .. + 3] with one 16-byte load and the
+// same four k of W's row 16 a + i from LDS: MFMA step s of the group uses k = 16 t + 4 kk + s on both
+// operands.  Register q of the result is out[row 4 kk + q][16 a + i].
+template <int NT, int ACT>
+__global__ __launch_bounds__(512) void linear_narrow_fwd_kernel(int64_t m, int K, int n_out, const float* __restrict__ x,
+                                                                int64_t ldx, const float* __restrict__ W,
+                                                                const float* __restrict__ b, float* __restrict__ out,
+                                                                int64_t ldo) {
+    extern __shared__ float Ws[];  // [NT * 16][K + 4]
+    const int KS = K + 4;
+    const int k4 = K >> 2;
+    for (int e = threadIdx.x; e < NT * 16 * k4; e += 512) {
+        const int n = e / k4, c4 = e - n * k4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < n_out) v = *reinterpret_cast<const float4*>(W + (int64_t)n * K + 4 * c4);
+        *reinterpret_cast<float4*>(Ws + n * KS + 4 * c4) = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, kk = lane >> 4;
+    const int64_t ntiles = (m + 15) / 16;
+    float bias[NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) bias[a] = (16 * a + i < n_out) ? b[16 * a + i] : 0.f;
+    for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 8) {
+        const int64_t r = min(tile * 16 + i, m - 1);
+        const float* xp = x + r * ldx + 4 * kk;
+        const float* wp = Ws + i * KS + 4 * kk;
+        v4f acc[NT];
+#pragma unroll
+        for (int a = 0; a < NT; ++a) acc[a] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int t = 0; t < (K >> 4); ++t) {
+            const float4 xa = *reinterpret_cast<const float4*>(xp + 16 * t);
+#pragma unroll
+            for (int a = 0; a < NT; ++a) {
+                const float4 w = *reinterpret_cast<const float4*>(wp + 16 * a * KS + 16 * t);
+                acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, w.x, acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, w.y, acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, w.z, acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, w.w, acc[a], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+            const int c = 16 * a + i;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t row = tile * 16 + 4 * kk + q;
+                if (row < m && c < n_out) {
+                    float v = acc[a][q] + bias[a];
+                    if (ACT == ACT_TANH) v = tanhf(v);
+                    if (ACT == ACT_RELU) v = fmaxf(v, 0.f);
+                    out[row * ldo + c] = v;
+                }
+            }
+        }
+    }
+}
+
+// dx = (g W) * [hprev > 0] and the column sums of dx, for a narrow g (n_out <= 64 columns): the input
+// gradient of the MLP's last layer fused with the ReLU derivative and the bias gradient of the layer
+// before it.  Workgroup = (64-column block of dx, chunk of rows); the block's slice of W lives in
+// registers for the whole chunk.  Lane l = (j = l & 15, kk = l >> 4); product tile t holds the OUTPUT
+// columns 4 j + t of the block, so register q of the four tiles is dx[row 4 kk + q][4 j .. 4 j + 3]: one
+// 16-byte load of hprev and one 16-byte store per row.
+template <int NT>
+__global__ __launch_bounds__(256) void dgrad_narrow_relu_kernel(int64_t m, int n_out, int N, const float* __restrict__ g,
+                                                                int64_t ldg, const float* __restrict__ W,
+                                                                const float* __restrict__ hprev, int64_t ldh,
+                                                                float* __restrict__ dx, int64_t ldx,
+                                                                float* __restrict__ partial, int64_t rows_per_block) {
+    __shared__ float red[4][16][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, kk = lane >> 4;
+    const int c0 = blockIdx.x * 64;
+    // B operand: W[k][c0 + 4 j + t] for k = 4 s + kk, s = 0 .. NT * 4 - 1
+    float wb[NT * 4][4];
+#pragma unroll
+    for (int s_ = 0; s_ < NT * 4; ++s_) {
+        const int k = 4 * s_ + kk;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < n_out) v = *reinterpret_cast<const float4*>(W + (int64_t)k * N + c0 + 4 * j);
+        wb[s_][0] = v.x; wb[s_][1] = v.y; wb[s_][2] = v.z; wb[s_][3] = v.w;
+    }
+    const int64_t b0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t b1 = min(m, b0 + rows_per_block);
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t r0 = b0 + 16 * wave; r0 < b1; r0 += 64) {
+        const int64_t ra = min(r0 + j, m - 1);   // A operand row of this lane
+        float ga[NT * 4];
+#pragma unroll
+        for (int s_ = 0; s_ < NT * 4; ++s_) {
+            const int k = 4 * s_ + kk;
+            ga[s_] = g[ra * ldg + min(k, n_out - 1)];
+        }
+        float4 hm[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t row = min(r0 + 4 * kk + q, m - 1);
+            hm[q] = *reinterpret_cast<const float4*>(hprev + row * ldh + c0 + 4 * j);
+        }
+        v4f acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s_ = 0; s_ < NT * 4; ++s_) {
+            const float a = (4 * s_ + kk < n_out) ? ga[s_] : 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wb[s_][t], acc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t row = r0 + 4 * kk + q;
+            if (row < b1) {
+                float4 o;
+                o.x = hm[q].x > 0.f ? acc[0][q] : 0.f;
+                o.y = hm[q].y > 0.f ? acc[1][q] : 0.f;
+                o.z = hm[q].z > 0.f ? acc[2][q] : 0.f;
+                o.w = hm[q].w > 0.f ? acc[3][q] : 0.f;
+                *reinterpret_cast<float4*>(dx + row * ldx + c0 + 4 * j) = o;
+                csum[0] += o.x; csum[1] += o.y; csum[2] += o.z; csum[3] += o.w;
+            }
+        }
+    }
+    // column sums: the four row groups of a wave, then the four waves, in fixed order
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        csum[t] += __shfl_xor(csum[t], 16);
+        csum[t] += __shfl_xor(csum[t], 32);
+    }
+    if (kk == 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) red[wave][j][t] = csum[t];
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int jj = threadIdx.x >> 2, t = threadIdx.x & 3;
+        const float s = ((red[0][jj][t] + red[1][jj][t]) + red[2][jj][t]) + red[3][jj][t];
+        partial[(int64_t)blockIdx.y * N + c0 + 4 * jj + t] = s;
+    }
+}
+
 constexpr int WGRAD_CHUNKS = 128;     // most row chunks of one product
 constexpr int WGRAD_CHUNK_ROWS = 256; // fewest rows of a chunk
 
@@ -355,4 +500,84 @@ extern "C" int sparc_first_layer_bwd(int64_t m, int din, int n, const float* x, 
     if (m == 0)
         return hipMemsetAsync(dWt_db, 0, (size_t)(din + 1) * n * sizeof(float), stream) == hipSuccess ? SPARC_OK : SPARC_ERR_LAUNCH;
     return wgrad_launch(true, m, din, din + 1, n, x, ldx, g, ldg, h, ldh, dWt_db, ws, stream);
+}
+
+extern "C" int sparc_linear_narrow_fwd(int64_t m, int K, int n_out, int act, const float* x, int64_t ldx, const float* W,
+                                       const float* b, float* out, int64_t ldo, sparc_stream_t stream) {
+    if (m < 0 || K <= 0 || K % 16 != 0 || n_out <= 0 || n_out > SPARC_MAX_K || (act != ACT_RELU && act != ACT_TANH && act != 2) ||
+        !x || !W || !b || !out || ldx < K || ldx % 4 != 0 || ldo < n_out || !aligned16(x) || !aligned16(W))
+        return SPARC_ERR_ARG;
+    const int nt = (n_out + 15) / 16;
+    const size_t lds = (size_t)nt * 16 * (K + 4) * sizeof(float);
+    if (lds > 150 * 1024) return SPARC_ERR_ARG;   // the weight matrix must fit the LDS of one CU
+    if (m == 0) return SPARC_OK;
+    const int64_t ntiles = (m + 15) / 16;
+    int64_t nb = (ntiles + 7) / 8;
+    if (nb > 256) nb = 256;
+    dim3 grid((unsigned)nb), block(512);
+#define SPARC_FWD(NT_, A_)                                                                                               \
+    do {                                                                                                                 \
+        static bool configured = false;                                                                                  \
+        if (!configured) {                                                                                               \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_narrow_fwd_kernel<NT_, A_>),                   \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)              \
+                return SPARC_ERR_LAUNCH;                                                                                 \
+            configured = true;                                                                                           \
+        }                                                                                                                \
+        hipLaunchKernelGGL((linear_narrow_fwd_kernel<NT_, A_>), grid, block, lds, stream, m, K, n_out, x, ldx, W, b, out, ldo); \
+    } while (0)
+#define SPARC_FWD_ACT(NT_)                                    \
+    do {                                                      \
+        if (act == ACT_RELU) SPARC_FWD(NT_, ACT_RELU);        \
+        else if (act == ACT_TANH) SPARC_FWD(NT_, ACT_TANH);   \
+        else SPARC_FWD(NT_, 2);                               \
+    } while (0)
+    switch (nt) {
+        case 1: SPARC_FWD_ACT(1); break;
+        case 2: SPARC_FWD_ACT(2); break;
+        case 3: SPARC_FWD_ACT(3); break;
+        default: SPARC_FWD_ACT(4); break;
+    }
+#undef SPARC_FWD_ACT
+#undef SPARC_FWD
+    SPARC_CHECK_LAUNCH();
+    return SPARC_OK;
+}
+
+namespace {
+constexpr int DGRAD_CHUNKS = 256;
+int64_t dgrad_rows_per_block(int64_t m) {
+    int64_t rpb = (m + DGRAD_CHUNKS - 1) / DGRAD_CHUNKS;
+    rpb = (rpb + 63) / 64 * 64;
+    return rpb < 64 ? 64 : rpb;
+}
+}  // namespace
+
+extern "C" size_t sparc_dgrad_narrow_relu_workspace_bytes(int64_t m, int N) {
+    if (m < 0 || N <= 0) return 0;
+    return sparc_align_up((size_t)DGRAD_CHUNKS * (size_t)N * sizeof(float)) + 256;
+}
+
+extern "C" int sparc_dgrad_narrow_relu(int64_t m, int n_out, int N, const float* g, int64_t ldg, const float* W,
+                                       const float* hprev, int64_t ldh, float* dx, int64_t ldx, float* db_prev, void* ws,
+                                       size_t ws_bytes, sparc_stream_t stream) {
+    if (m < 0 || n_out <= 0 || n_out > SPARC_MAX_K || N <= 0 || N % 64 != 0 || !g || !W || !hprev || !dx || !db_prev ||
+        ldg < n_out || ldh < N || ldx < N || ldh % 4 != 0 || ldx % 4 != 0 || !aligned16(W) || !aligned16(hprev) || !aligned16(dx))
+        return SPARC_ERR_ARG;
+    if (ws_bytes < sparc_dgrad_narrow_relu_workspace_bytes(m, N) || !ws || (reinterpret_cast<uintptr_t>(ws) & 255)) return SPARC_ERR_WS;
+    if (m == 0) return hipMemsetAsync(db_prev, 0, (size_t)N * sizeof(float), stream) == hipSuccess ? SPARC_OK : SPARC_ERR_LAUNCH;
+    const int64_t rpb = dgrad_rows_per_block(m);
+    const int nparts = (int)((m + rpb - 1) / rpb);
+    float* partial = static_cast<float*>(ws);
+    dim3 grid(N / 64, nparts);
+    switch ((n_out + 15) / 16) {
+        case 1: hipLaunchKernelGGL((dgrad_narrow_relu_kernel<1>), grid, dim3(256), 0, stream, m, n_out, N, g, ldg, W, hprev, ldh, dx, ldx, partial, rpb); break;
+        case 2: hipLaunchKernelGGL((dgrad_narrow_relu_kernel<2>), grid, dim3(256), 0, stream, m, n_out, N, g, ldg, W, hprev, ldh, dx, ldx, partial, rpb); break;
+        case 3: hipLaunchKernelGGL((dgrad_narrow_relu_kernel<3>), grid, dim3(256), 0, stream, m, n_out, N, g, ldg, W, hprev, ldh, dx, ldx, partial, rpb); break;
+        default: hipLaunchKernelGGL((dgrad_narrow_relu_kernel<4>), grid, dim3(256), 0, stream, m, n_out, N, g, ldg, W, hprev, ldh, dx, ldx, partial, rpb); break;
+    }
+    SPARC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(colsum_finish, dim3((N + 63) / 64), dim3(64 * COLSUM_LANES), 0, stream, nparts, N, partial, db_prev);
+    SPARC_CHECK_LAUNCH();
+    return SPARC_OK;
 }

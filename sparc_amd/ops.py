@@ -86,6 +86,109 @@ def first_layer_bwd(x: torch.Tensor, g: torch.Tensor, h: torch.Tensor):
     return out[:din].t(), out[din]
 
 
+def linear_narrow_fwd(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, act: int):
+    """act(x W^T + b) on the MFMA kernel for a narrow output layer, or None when the shape does not fit it."""
+    m, K = x.shape
+    n_out = W.shape[0]
+    if (K % 16 or n_out > 64 or ((n_out + 15) // 16) * 16 * (K + 4) * 4 > 150 * 1024 or not x.is_contiguous()
+            or not W.is_contiguous() or x.data_ptr() % 16 or W.data_ptr() % 16 or x.dtype != torch.float32):
+        return None
+    out = torch.empty(m, n_out, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.sparc_linear_narrow_fwd(m, K, n_out, int(act), _ptr(x), x.stride(0), _ptr(W), _ptr(b), _ptr(out), n_out,
+                                          _stream()), "sparc_linear_narrow_fwd")
+    return out
+
+
+def dgrad_narrow_relu(g: torch.Tensor, W: torch.Tensor, hprev: torch.Tensor):
+    """((g W) * [hprev > 0], its column sums): input gradient of a narrow layer fused with the ReLU
+    derivative and bias gradient of the layer before it."""
+    m, n_out = g.shape
+    N = W.shape[1]
+    dx = torch.empty(m, N, dtype=torch.float32, device=g.device)
+    db = torch.empty(N, dtype=torch.float32, device=g.device)
+    nbytes = lib.sparc_dgrad_narrow_relu_workspace_bytes(m, N)
+    ws = Workspace.get(nbytes, g.device)
+    with torch.cuda.device(g.device):
+        check(lib.sparc_dgrad_narrow_relu(m, n_out, N, _ptr(g), g.stride(0), _ptr(W), _ptr(hprev), hprev.stride(0), _ptr(dx), N,
+                                          _ptr(db), _ptr(ws), nbytes, _stream()), "sparc_dgrad_narrow_relu")
+    return dx, db
+
+
+class SpectralMLP(torch.autograd.Function):
+    """The whole SpectralNet MLP (src/SpectralTrainer.py:28-39, :96-97): Linear+ReLU layers and a final
+    Linear+Tanh, forward and backward written out so that neighbouring steps share a pass:
+    bias+ReLU ride in the epilogue of the wide forward products; the narrow output layer runs on the
+    MFMA kernels (forward, weight gradient, input gradient fused with the previous layer's ReLU
+    derivative and bias gradient); the first layer's backward is one pass that never writes the
+    masked gradient.  The wide products stay library GEMMs.  Arguments: x, W1, b1, ..., WL, bL."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        require_gpu(x.device)
+        Ws, bs = params[0::2], params[1::2]
+        acts = [x]
+        for W, b in zip(Ws[:-1], bs[:-1]):
+            acts.append(torch._addmm_activation(b, acts[-1], W.t()))
+        y = linear_narrow_fwd(acts[-1], Ws[-1], bs[-1], ACT_TANH)
+        if y is None:
+            y = torch.addmm(bs[-1], acts[-1], Ws[-1].t()).tanh_()
+        ctx.save_for_backward(*acts, y, *Ws)
+        ctx.n_layers = len(Ws)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = ctx.n_layers
+        saved = ctx.saved_tensors
+        acts, y, Ws = saved[:L], saved[L], saved[L + 1:]
+        grads = [None] * (2 * L)
+        need_x = ctx.needs_input_grad[0]
+        # output layer: tanh derivative + bias gradient, weight gradient, input gradient (+ previous ReLU)
+        gp, db = act_bwd_bias(_f32c(gy), y, ACT_TANH)
+        grads[2 * (L - 1)] = _wgrad(gp, acts[L - 1], Ws[L - 1])
+        grads[2 * (L - 1) + 1] = db
+        gx = None
+        if L == 1:
+            gx = gp.mm(Ws[0]) if need_x else None
+            return (gx, *grads)
+        # gradient reaching the output of hidden layer L-2: already multiplied by its ReLU derivative
+        # (with its bias gradient) when the fused kernel applies, raw otherwise
+        W, h = Ws[L - 1], acts[L - 1]
+        if W.shape[0] <= 64 and W.shape[1] % 64 == 0 and W.is_contiguous() and W.data_ptr() % 16 == 0:
+            pending = dgrad_narrow_relu(gp, W, h)
+        else:
+            pending = gp.mm(W)
+        for l in range(L - 2, -1, -1):   # hidden layers, last to first; acts[l] is layer l's input, acts[l + 1] its output
+            if isinstance(pending, tuple):
+                gp, db = pending
+            else:
+                xin, hout = acts[l], acts[l + 1]
+                if (l == 0 and not need_x and xin.shape[1] < 64 and hout.shape[1] % 64 == 0 and xin.stride(1) == 1
+                        and xin.dtype == torch.float32 and pending.data_ptr() % 16 == 0):
+                    dWt, db = first_layer_bwd(xin, pending, hout)
+                    grads[0], grads[1] = dWt, db
+                    return (None, *grads)
+                gp, db = act_bwd_bias(pending, hout, ACT_RELU)
+            grads[2 * l] = _wgrad(gp, acts[l], Ws[l])
+            grads[2 * l + 1] = db
+            if l > 0:
+                pending = gp.mm(Ws[l])
+            elif need_x:
+                gx = gp.mm(Ws[0])
+        return (gx, *grads)
+
+
+def _wgrad(gp: torch.Tensor, xin: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
+    """gp^T xin, on the MFMA kernel when one side is narrow."""
+    n_out, n_in = W.shape
+    if n_out <= 64 and n_in % 64 == 0 and xin.is_contiguous() and xin.data_ptr() % 16 == 0:
+        return wgrad_small(gp, xin)
+    if n_in <= 64 and n_out % 64 == 0 and gp.data_ptr() % 16 == 0:
+        return wgrad_small(xin, gp).t()
+    return gp.t().mm(xin)
+
+
 class LinearAct(torch.autograd.Function):
     """act(x W^T + b) of one MLP layer (src/SpectralTrainer.py:28-39): the products are library
     GEMMs (bias and ReLU in the forward product's epilogue); the activation derivative, the bias

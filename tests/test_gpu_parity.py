@@ -363,6 +363,60 @@ def test_first_layer_backward_matches_float64(dev, m, din, n):
     assert rel(db.cpu().numpy(), gp.sum(0).numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("m,K,n_out,act", [(3001, 512, 47, 1), (17, 16, 1, 0), (24491, 512, 64, 2), (100, 768, 33, 1)])
+def test_linear_narrow_fwd_matches_float64(dev, m, K, n_out, act):
+    from sparc_amd.ops import linear_narrow_fwd
+    gen = torch.Generator().manual_seed(m + K)
+    x = torch.randn(m, K, generator=gen)
+    W = torch.randn(n_out, K, generator=gen) / K ** 0.5
+    b = torch.randn(n_out, generator=gen)
+    pre = x.double() @ W.double().t() + b.double()
+    want = (torch.relu(pre), torch.tanh(pre), pre)[act]
+    got = linear_narrow_fwd(x.to(dev), W.to(dev), b.to(dev), act)
+    assert got is not None and got.shape == (m, n_out)
+    assert rel(got.cpu().numpy(), want.numpy()) < 1e-5
+    # a weight matrix that does not fit the LDS of one CU is left to the library product
+    assert linear_narrow_fwd(torch.randn(8, 1024, device=dev), torch.randn(33, 1024, device=dev), torch.randn(33, device=dev), 1) is None
+
+
+@pytest.mark.parametrize("m,n_out,N", [(3001, 47, 512), (70, 64, 64), (5, 1, 128), (24491, 33, 256)])
+def test_dgrad_narrow_relu_matches_float64(dev, m, n_out, N):
+    from sparc_amd.ops import dgrad_narrow_relu
+    gen = torch.Generator().manual_seed(m + N)
+    g = torch.randn(m, n_out, generator=gen)
+    W = torch.randn(n_out, N, generator=gen)
+    h = torch.relu(torch.randn(m, N, generator=gen))
+    want = torch.where(h > 0, g.double() @ W.double(), torch.zeros((), dtype=torch.float64))
+    dx, db = dgrad_narrow_relu(g.to(dev), W.to(dev), h.to(dev))
+    assert rel(dx.cpu().numpy(), want.numpy()) < 1e-5
+    assert torch.equal(dx.cpu() == 0, want == 0) or float(((dx.cpu() == 0) != (want == 0)).float().mean()) < 1e-6
+    assert rel(db.cpu().numpy(), want.sum(0).numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("dims,x_grad", [((10, 128, 64, 64, 47), False), ((100, 64, 8), True), ((7, 5, 3), False),
+                                          ((12, 9), True)])
+def test_spectral_mlp_matches_torch_layers(dev, dims, x_grad):
+    """The whole-MLP function (every fused path and every fallback) against torch.nn layers."""
+    from sparc_amd.ops import SpectralMLP
+    torch.manual_seed(len(dims))
+    lins = [torch.nn.Linear(a, b).to(dev) for a, b in zip(dims[:-1], dims[1:])]
+    m = 1537
+    x = torch.randn(m, dims[0], device=dev, requires_grad=x_grad)
+    t = torch.randn(m, dims[-1], device=dev)
+    h = x
+    for lin in lins[:-1]:
+        h = torch.relu(lin(h))
+    ref = torch.tanh(lins[-1](h))
+    params = [p for lin in lins for p in (lin.weight, lin.bias)]
+    wrt = params + ([x] if x_grad else [])
+    rg = torch.autograd.grad((ref * t).sum(), wrt)
+    out = SpectralMLP.apply(x, *params)
+    og = torch.autograd.grad((out * t).sum(), wrt)
+    assert rel(out.detach().cpu().numpy(), ref.detach().cpu().numpy()) < 1e-5
+    for a, b in zip(og, rg):
+        assert a.shape == b.shape and rel(a.cpu().numpy(), b.cpu().numpy()) < 1e-4
+
+
 def test_linear_act_first_layer_path(dev):
     """A Linear+ReLU layer on an input that needs no gradient takes the one-pass backward."""
     from sparc_amd.ops import LinearAct
