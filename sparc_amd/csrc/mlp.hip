@@ -251,9 +251,9 @@ __global__ __launch_bounds__(256) void wgrad_finish(int nchunks, int n_out, int 
 
 // out = act(x W^T + b) for a narrow output (n_out <= 64): the MLP's last layer.  W (n_out x K, zero
 // padded to NT * 16 rows) sits in LDS with a 4-float row pad; a wave produces 16 rows at a time.
-// Lane l = (i = l & 15, kk = l >> 4) reads x[row i][16 t + 4 kk .. + 3] with one 16-byte load and the
-// same four k of W's row 16 a + i from LDS: MFMA step s of the group uses k = 16 t + 4 kk + s on both
-// operands.  Register q of the result is out[row 4 kk + q][16 a + i].
+// Lane l = (i = l & 15, kk = l >> 4) reads a run of consecutive k of x's row i and the same k of W's
+// row 16 a + i from LDS; every MFMA step uses one k of the run on both operands (the order of k inside
+// the sum is free).  Register q of the result is out[row 4 kk + q][16 a + i].
 template <int NT, int ACT>
 __global__ __launch_bounds__(512) void linear_narrow_fwd_kernel(int64_t m, int K, int n_out, const float* __restrict__ x,
                                                                 int64_t ldx, const float* __restrict__ W,
@@ -277,21 +277,58 @@ __global__ __launch_bounds__(512) void linear_narrow_fwd_kernel(int64_t m, int K
     for (int a = 0; a < NT; ++a) bias[a] = (16 * a + i < n_out) ? b[16 * a + i] : 0.f;
     for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 8) {
         const int64_t r = min(tile * 16 + i, m - 1);
-        const float* xp = x + r * ldx + 4 * kk;
-        const float* wp = Ws + i * KS + 4 * kk;
+        // 64 consecutive k per group: lane (i, kk) reads x[row i][64 T + 16 kk .. + 15] (64 contiguous
+        // bytes, a whole 256-byte line per row and wave instruction) and the same k of W's rows
+        const float* xp = x + r * ldx + 16 * kk;
+        const float* wp = Ws + i * KS + 16 * kk;
         v4f acc[NT];
 #pragma unroll
         for (int a = 0; a < NT; ++a) acc[a] = v4f{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-        for (int t = 0; t < (K >> 4); ++t) {
-            const float4 xa = *reinterpret_cast<const float4*>(xp + 16 * t);
+        const int groups = K >> 6;
+        v4f bufA[4], bufB[4];
+        auto request = [&](v4f (&dst)[4], const int T) {   // T clamped: the last request is a harmless repeat
+            const float* p = xp + 64 * min(T, groups - 1);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) dst[u] = *reinterpret_cast<const v4f*>(p + 4 * u);
+            __builtin_amdgcn_sched_barrier(0);   // the requests stay ahead of the products that follow
+        };
+        auto products = [&](const v4f (&xa)[4], const int T) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float4 w[NT];
+#pragma unroll
+                for (int a = 0; a < NT; ++a) w[a] = *reinterpret_cast<const float4*>(wp + 16 * a * KS + 64 * T + 4 * u);
+#pragma unroll
+                for (int a = 0; a < NT; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u][0], w[a].x, acc[a], 0, 0, 0);
+#pragma unroll
+                for (int a = 0; a < NT; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u][1], w[a].y, acc[a], 0, 0, 0);
+#pragma unroll
+                for (int a = 0; a < NT; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u][2], w[a].z, acc[a], 0, 0, 0);
+#pragma unroll
+                for (int a = 0; a < NT; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u][3], w[a].w, acc[a], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // Two register buffers: a group's run arrives while the other group's products run.  The loop body
+        // has no branch between a request and its use (the optimiser sinks a request into a conditional use).
+        if (groups > 0) request(bufA, 0);
+        int T = 0;
+        for (; T + 2 <= groups; T += 2) {
+            request(bufB, T + 1);
+            products(bufA, T);
+            request(bufA, T + 2);
+            products(bufB, T + 1);
+        }
+        if (T < groups) products(bufA, T);
+        for (int t = groups * 4 + 0; t < (K >> 4); ++t) {   // K not a multiple of 64: 16 k at a time, 4 per lane
+            const float4 xr = *reinterpret_cast<const float4*>(x + r * ldx + 16 * t + 4 * kk);
 #pragma unroll
             for (int a = 0; a < NT; ++a) {
-                const float4 w = *reinterpret_cast<const float4*>(wp + 16 * a * KS + 16 * t);
-                acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, w.x, acc[a], 0, 0, 0);
-                acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, w.y, acc[a], 0, 0, 0);
-                acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, w.z, acc[a], 0, 0, 0);
-                acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, w.w, acc[a], 0, 0, 0);
+                const float4 w = *reinterpret_cast<const float4*>(Ws + (16 * a + i) * KS + 16 * t + 4 * kk);
+                acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr.x, w.x, acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr.y, w.y, acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr.z, w.z, acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr.w, w.w, acc[a], 0, 0, 0);
             }
         }
 #pragma unroll
