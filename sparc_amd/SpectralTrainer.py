@@ -92,9 +92,7 @@ class SpectralNetLoss(nn.Module):
     def forward(self, W, Y: torch.Tensor, is_normalized: bool = False) -> torch.Tensor:
         if not isinstance(W, ClusterBatch):
             raise TypeError("W must be a sparc_amd.graph.ClusterBatch (build one with ClusterBatch.from_support)")
-        if not is_normalized:
-            raise NotImplementedError("only is_normalized=True is on the training path (src/SpectralTrainer.py:235, :257)")
-        return LapLoss.apply(Y, W)
+        return LapLoss.apply(Y, W, bool(is_normalized))
 
 
 class SpectralTrainer:

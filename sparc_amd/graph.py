@@ -283,8 +283,11 @@ class ClusterBatch:
         return self
 
     # ---- per-step work -------------------------------------------------------------------
-    def lap(self, Y: torch.Tensor, want_grad: bool):
-        """loss (float64 0-d tensor) and d loss / d Y (or None) for is_normalized=True."""
+    def lap(self, Y: torch.Tensor, want_grad: bool, normalized: bool = True):
+        """loss (float64 0-d tensor) and d loss / d Y (or None): the reference's is_normalized=True branch
+        (Yn = Y / sqrt(d), src/SpectralTrainer.py:132-135), or with normalized=False the plain one (Yn = Y):
+        the kernels take 1/sqrt(d) from the per-row record only, so the plain branch is the same pass over a
+        copy of the records whose 1/sqrt(d) field is 1."""
         if Y.dim() != 2 or Y.shape[0] != self.m:
             raise ValueError(f"Y must be [{self.m}, k], got {tuple(Y.shape)}")
         k = int(Y.shape[1])
@@ -302,8 +305,14 @@ class ClusterBatch:
         nbytes = lib.sparc_lap_workspace_bytes(self.m, k, ntiles)
         ws = Workspace.get(nbytes, self.device)
         with torch.cuda.device(self.device):
+            rowc = self.rowc
+            if not normalized:
+                if getattr(self, "_rowc_plain", None) is None:
+                    self._rowc_plain = self.rowc.clone()
+                    self._rowc_plain[:, 3] = 1.0
+                rowc = self._rowc_plain
             check(lib.sparc_lap_fwd(self.m, self.nnz, _ptr(self.rowptr), _ptr(self.colidx), _ptr(self.val),
-                                    _ptr(self.valT), _ptr(self.rowc), _ptr(self.coupling), k, k, _ptr(Y), _ptr(loss),
+                                    _ptr(self.valT), _ptr(rowc), _ptr(self.coupling), k, k, _ptr(Y), _ptr(loss),
                                     _ptr(grad), _ptr(tiles), ntiles, tile_rows, _ptr(ws), nbytes, _stream()),
                   "sparc_lap_fwd")
         return loss, grad

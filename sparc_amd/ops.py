@@ -323,16 +323,16 @@ class OrthApply(torch.autograd.Function):
 
 
 class LapLoss(torch.autograd.Function):
-    """Spectral loss with is_normalized=True on a ClusterBatch (src/SpectralTrainer.py:130-137).
+    """Spectral loss on a ClusterBatch (src/SpectralTrainer.py:130-137), either branch of is_normalized.
 
     The gradient with respect to Y falls out of the same pass as the loss (the forward
     and the transposed product share one sweep over the CSR), so backward only scales it.
     """
 
     @staticmethod
-    def forward(ctx, Y, batch: ClusterBatch):
+    def forward(ctx, Y, batch: ClusterBatch, normalized: bool = True):
         want = bool(ctx.needs_input_grad[0])
-        loss, grad = batch.lap(Y, want)
+        loss, grad = batch.lap(Y, want, normalized)
         if want:
             ctx.save_for_backward(grad)
         return loss.to(torch.float32)
@@ -340,4 +340,4 @@ class LapLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gl):
         (grad,) = ctx.saved_tensors
-        return grad * gl, None
+        return grad * gl, None, None

@@ -114,6 +114,15 @@ def test_affinity_and_loss_match_reference_golden(dev, golden, name):
     loss = SpectralNetLoss()(b, Y, is_normalized=True)
     assert loss.dtype == torch.float32
     assert rel(loss.item(), g[name + "_loss_norm"]) < TOL
+    plain = SpectralNetLoss()(b, Y)                      # is_normalized defaults to False, as in the reference
+    assert rel(plain.item(), g[name + "_loss_plain"]) < TOL
+    # gradient of the plain branch against autograd through the dense oracle
+    W = O.valid_affinity(O.support_to_dense(sup(g, name + "_"), torch.float64))
+    Yd = torch.tensor(g["Y"], dtype=torch.float64, requires_grad=True)
+    (gref,) = torch.autograd.grad(O.spectral_loss(W, Yd, False), Yd)
+    Yg = Y.clone().requires_grad_(True)
+    SpectralNetLoss()(b, Yg, is_normalized=False).backward()
+    assert rel(Yg.grad.cpu().numpy(), gref.numpy()) < TOL
 
 
 @pytest.mark.parametrize("k", [1, 8, 16, 17, 32, 47, 64])
