@@ -118,16 +118,36 @@ __global__ void gram_reduce(int kk, int nparts, const double* __restrict__ slab,
     G[e] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
 }
 
+// 1 / sqrt(x) in float64: the hardware estimate refined by two Newton steps
+__device__ __forceinline__ double fast_rsqrt(const double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    y = y * (1.5 - 0.5 * x * y * y);
+    return y;
+}
+
+// 1 / x in float64: the hardware estimate refined by two Newton steps
+__device__ __forceinline__ double fast_rcp(const double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = y * (2.0 - x * y);
+    y = y * (2.0 - x * y);
+    return y;
+}
+
 constexpr int KLD = SPARC_MAX_K + 1;  // leading dimension of the k x k LDS images (bank-conflict free columns)
 
-// Single workgroup of 4 waves.  LDS images (padded leading dimension): R (Gram, then its Cholesky
-// factor, upper), X = R^-1, T (top rows of Yt), Q (Yt[top] X and its sign-tracking LU).
-__global__ __launch_bounds__(256) void orth_weights_kernel(int64_t m, int k, const double* __restrict__ G,
-                                                           const float* __restrict__ Yt, int64_t ld,
-                                                           const int32_t* __restrict__ top_idx, int mode,
-                                                           float* __restrict__ Wo, double* __restrict__ Rc_out,
-                                                           double* __restrict__ Rinv_out, double* __restrict__ signs_out,
-                                                           int32_t* __restrict__ info) {
+constexpr int OW_THREADS = 1024;
+
+// Single workgroup of 16 waves; every phase is bound by LDS latency, so the trailing updates give each
+// thread at most 2 x 2 elements, fully unrolled.  LDS images (padded leading dimension): R (Gram, then
+// its Cholesky factor, upper), X = R^-1, T (top rows of Yt), Q (scaled pivot rows during the
+// factorisation, then Yt[top] X and its sign-tracking LU).
+__global__ __launch_bounds__(OW_THREADS) void orth_weights_kernel(int64_t m, int k, const double* __restrict__ G,
+                                                                  const float* __restrict__ Yt, int64_t ld,
+                                                                  const int32_t* __restrict__ top_idx, int mode,
+                                                                  float* __restrict__ Wo, double* __restrict__ Rc_out,
+                                                                  double* __restrict__ Rinv_out,
+                                                                  double* __restrict__ signs_out, int32_t* __restrict__ info) {
     __shared__ double R[SPARC_MAX_K * KLD];
     __shared__ double X[SPARC_MAX_K * KLD];
     __shared__ double Q[SPARC_MAX_K * KLD];
@@ -135,12 +155,11 @@ __global__ __launch_bounds__(256) void orth_weights_kernel(int64_t m, int k, con
     __shared__ double sg[SPARC_MAX_K];
     __shared__ int bad;
     const int tid = threadIdx.x;
-    const int ty = tid >> 4, tx = tid & 15;  // 16 x 16 thread grid over the trailing matrix
+    const int ty = tid >> 5, tx = tid & 31;  // 32 x 32 thread grid over the trailing matrix
     if (tid == 0) bad = 0;
-    for (int e = tid; e < k * k; e += 256) {
+    for (int e = tid; e < k * k; e += OW_THREADS) {
         const int i = e / k, j = e % k;
         R[i * KLD + j] = G[e];
-        X[i * KLD + j] = 0.0;
         double y = 0.0;
         if (mode == 0) {
             const int64_t row = top_idx ? top_idx[i] : i;
@@ -150,62 +169,141 @@ __global__ __launch_bounds__(256) void orth_weights_kernel(int64_t m, int k, con
     }
     __syncthreads();
 
-    // Cholesky, upper: G = R^T R.  Two barriers per column: scale the pivot row, update the trailing
-    // triangle (every thread derives the pivot itself, so there is no separate pivot phase).
+    // Cholesky, upper: G = R^T R, ONE barrier per column.  The working matrix R keeps the unscaled Schur
+    // complement; the scaled pivot row goes to its own image (Q doubles as that image until it is needed
+    // for the top rows), so the trailing update of column j never races with the scaling of row j:
+    //     R[a][b] -= R[j][a] R[j][b] / R[j][j]        factor row:  F[j][c] = R[j][c] / sqrt(R[j][j])
+    double* F = Q;
     for (int j = 0; j < k; ++j) {
         double piv = R[j * KLD + j];
         if (!(piv > 0.0)) {
             if (tid == 0 && !bad) bad = j + 1;
             piv = 1e-300;
         }
-        const double inv_dj = 1.0 / sqrt(piv);
-        __syncthreads();  // everyone has read the pivot before it is overwritten
-        for (int c = j + tid; c < k; c += 256) R[j * KLD + c] = (c == j) ? piv * inv_dj : R[j * KLD + c] * inv_dj;
-        __syncthreads();
-        for (int a2 = j + 1 + ty; a2 < k; a2 += 16) {
-            const double f = R[j * KLD + a2];
-            for (int b2 = j + 1 + tx; b2 < k; b2 += 16)
-                if (a2 <= b2) R[a2 * KLD + b2] -= f * R[j * KLD + b2];
+        const double rs = fast_rsqrt(piv);   // 1 / sqrt(piv)
+        const double ip = rs * rs;           // 1 / piv
+        if (tid < k - j) F[j * KLD + j + tid] = R[j * KLD + j + tid] * rs;
+        // trailing update: LDS instruction issue bounds a step, so waves whose rows lie outside the
+        // trailing matrix skip it, and the 2 x 2 form is only used while the matrix is wider than 32
+        const int a0 = j + 1 + ty, b0 = j + 1 + tx;
+        if (j + 1 + 2 * (tid >> 6) < k) {              // wave-uniform
+            if (k - (j + 1) > 32) {                    // uniform
+                double fa[2], rb[2], cur[2][2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    fa[u] = (a0 + 32 * u < k) ? R[j * KLD + a0 + 32 * u] : 0.0;
+                    rb[u] = (b0 + 32 * u < k) ? R[j * KLD + b0 + 32 * u] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int v = 0; v < 2; ++v) {
+                        const int a2 = a0 + 32 * u, b2 = b0 + 32 * v;
+                        cur[u][v] = (b2 < k && a2 <= b2) ? R[a2 * KLD + b2] : 0.0;
+                    }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int v = 0; v < 2; ++v) {
+                        const int a2 = a0 + 32 * u, b2 = b0 + 32 * v;
+                        if (b2 < k && a2 <= b2) R[a2 * KLD + b2] = cur[u][v] - fa[u] * ip * rb[v];
+                    }
+            } else if (b0 < k && a0 <= b0) {
+                R[a0 * KLD + b0] -= R[j * KLD + a0] * ip * R[j * KLD + b0];
+            }
         }
         __syncthreads();
     }
-    for (int e = tid; e < k * k; e += 256)
-        if (e / k > e % k) R[(e / k) * KLD + e % k] = 0.0;
+    for (int e = tid; e < k * k; e += OW_THREADS) {
+        const int i = e / k, j = e % k;
+        R[i * KLD + j] = (i <= j) ? F[i * KLD + j] : 0.0;
+    }
     __syncthreads();
 
-    // X = R^-1 (upper), one column per thread (its own column: no synchronisation inside)
-    if (tid < k) {
-        const int c = tid;
-        X[c * KLD + c] = 1.0 / R[c * KLD + c];
-        for (int i = c - 1; i >= 0; --i) {
-            double tsum = 0.0;
-            for (int l = i + 1; l <= c; ++l) tsum += R[i * KLD + l] * X[l * KLD + c];
-            X[i * KLD + c] = -tsum / R[i * KLD + i];
+    // X = R^-1 (upper): column c by back substitution on the 16 lanes of group c; lane r keeps the entries
+    // X[l][c], l = r (mod 16), in registers, so the solve itself needs no barrier
+    if (tid < k) sg[tid] = fast_rcp(R[tid * KLD + tid]);   // reciprocal diagonal, borrowed from the sign array
+    __syncthreads();
+    {
+        const int c = tid >> 4, r = tid & 15;
+        double xr[4] = {0.0, 0.0, 0.0, 0.0};   // X[r + 16 q][c]
+        if (c < k) {
+            for (int i = c; i >= 0; --i) {
+                double t = 0.0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int l = r + 16 * q;
+                    if (l > i && l <= c) t += R[i * KLD + l] * xr[q];
+                }
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) t += __shfl_xor(t, off);
+                const double xi = ((i == c) ? 1.0 - t : -t) * sg[i];
+                if ((i & 15) == r) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (q == (i >> 4)) xr[q] = xi;
+                }
+            }
+        }
+        if (c < k) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int l = r + 16 * q;
+                if (l < k) X[l * KLD + c] = (l <= c) ? xr[q] : 0.0;
+            }
         }
     }
     __syncthreads();
 
     if (mode == 0) {
         // Q = Yt[top] X
-        for (int e = tid; e < k * k; e += 256) {
+        for (int e = tid; e < k * k; e += OW_THREADS) {
             const int a2 = e / k, b2 = e % k;
-            double tsum = 0.0;
-            for (int l = 0; l <= b2; ++l) tsum += T[a2 * KLD + l] * X[l * KLD + b2];
-            Q[a2 * KLD + b2] = tsum;
+            double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+            int l = 0;
+            for (; l + 3 <= b2; l += 4) {
+                t0 += T[a2 * KLD + l] * X[l * KLD + b2];
+                t1 += T[a2 * KLD + l + 1] * X[(l + 1) * KLD + b2];
+                t2 += T[a2 * KLD + l + 2] * X[(l + 2) * KLD + b2];
+                t3 += T[a2 * KLD + l + 3] * X[(l + 3) * KLD + b2];
+            }
+            for (; l <= b2; ++l) t0 += T[a2 * KLD + l] * X[l * KLD + b2];
+            Q[a2 * KLD + b2] = (t0 + t1) + (t2 + t3);
         }
         __syncthreads();
-        // Householder signs from the modified LU of Q, two barriers per column
+        // Householder signs from the modified LU of Q, one barrier per column: only the sign sequence is
+        // wanted, so the multipliers are applied on the fly and never stored
         for (int i = 0; i < k; ++i) {
             const double qii = Q[i * KLD + i];
             const double sgn = qii > 0.0 ? -1.0 : 1.0;
-            const double inv_piv = 1.0 / (qii - sgn);
-            __syncthreads();
+            const double inv_piv = fast_rcp(qii - sgn);
             if (tid == 0) sg[i] = sgn;
-            for (int a2 = i + 1 + tid; a2 < k; a2 += 256) Q[a2 * KLD + i] *= inv_piv;
-            __syncthreads();
-            for (int a2 = i + 1 + ty; a2 < k; a2 += 16) {
-                const double f = Q[a2 * KLD + i];
-                for (int b2 = i + 1 + tx; b2 < k; b2 += 16) Q[a2 * KLD + b2] -= f * Q[i * KLD + b2];
+            const int a0 = i + 1 + ty, b0 = i + 1 + tx;
+            if (i + 1 + 2 * (tid >> 6) < k) {              // wave-uniform
+                if (k - (i + 1) > 32) {                    // uniform
+                    double fa[2], rb[2], cur[2][2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        fa[u] = (a0 + 32 * u < k) ? Q[(a0 + 32 * u) * KLD + i] : 0.0;
+                        rb[u] = (b0 + 32 * u < k) ? Q[i * KLD + b0 + 32 * u] : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int v = 0; v < 2; ++v) {
+                            const int a2 = a0 + 32 * u, b2 = b0 + 32 * v;
+                            cur[u][v] = (a2 < k && b2 < k) ? Q[a2 * KLD + b2] : 0.0;
+                        }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int v = 0; v < 2; ++v) {
+                            const int a2 = a0 + 32 * u, b2 = b0 + 32 * v;
+                            if (a2 < k && b2 < k) Q[a2 * KLD + b2] = cur[u][v] - fa[u] * inv_piv * rb[v];
+                        }
+                } else if (a0 < k && b0 < k) {
+                    Q[a0 * KLD + b0] -= Q[a0 * KLD + i] * inv_piv * Q[i * KLD + b0];
+                }
             }
             __syncthreads();
         }
@@ -215,7 +313,7 @@ __global__ __launch_bounds__(256) void orth_weights_kernel(int64_t m, int k, con
     __syncthreads();
 
     const double sq = sqrt(static_cast<double>(m));
-    for (int e = tid; e < k * k; e += 256) {
+    for (int e = tid; e < k * k; e += OW_THREADS) {
         const int i = e / k, j = e % k;
         const double x = X[i * KLD + j];
         Wo[e] = static_cast<float>(sq * sg[i] * x * sg[j]);
@@ -400,7 +498,7 @@ extern "C" int sparc_orth_weights(int64_t m, int k, const double* G, const float
     if (m <= 0 || k < 1 || k > SPARC_MAX_K || !G || !Yt || ld < k || !Wo || !Rc || !Rinv || !signs || !info ||
         (mode != 0 && mode != 1))
         return SPARC_ERR_ARG;
-    hipLaunchKernelGGL(orth_weights_kernel, dim3(1), dim3(256), 0, stream, m, k, G, Yt, ld, top_idx, mode, Wo, Rc, Rinv,
+    hipLaunchKernelGGL(orth_weights_kernel, dim3(1), dim3(OW_THREADS), 0, stream, m, k, G, Yt, ld, top_idx, mode, Wo, Rc, Rinv,
                        signs, info);
     SPARC_CHECK_LAUNCH();
     return SPARC_OK;
