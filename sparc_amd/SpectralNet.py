@@ -44,7 +44,7 @@ class SpectralNet:
         when the autoencoder stage is on, X itself otherwise."""
         if self.config.get("should_use_ae", False):
             X = self._encode_chunks(X)
-        return np.array(X.detach().cpu())
+        return X.detach().cpu().numpy().copy()
 
     def _encode_chunks(self, X: torch.Tensor, chunk_rows: int = 1 << 18) -> torch.Tensor:
         self.ae_net.eval()

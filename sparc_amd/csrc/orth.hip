@@ -335,6 +335,7 @@ __device__ void mm_kk(int k, const double* A, bool ta, const double* B, bool tb,
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+#pragma unroll 4
         for (int l = 0; l < k; ++l) {
             double av[4], bv[4];
 #pragma unroll

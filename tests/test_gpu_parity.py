@@ -710,3 +710,41 @@ def test_token_lists_match_oracle_larger(dev):
     got = spectral_token_lists(E, Fm, K, device=dev, chunk_rows=1000).numpy()
     assert np.abs(got - want).max() < 2e-5
     assert np.allclose(got[:, -1, :], Fm.mean(0, keepdims=True), atol=1e-5)
+
+
+def test_facade_fit_predict_with_autoencoder(dev, golden, tmp_path, monkeypatch, capsys):
+    """SpectralNet.fit with should_use_ae: autoencoder stage, SpectralNet stage on its codes, predict / embed
+    on all nodes (src/SpectralNet.py:25-98), and the results writer."""
+    from sparc_amd.SpectralNet import SpectralNet, save_results
+    g = golden("g8_trainer.npz")
+    monkeypatch.chdir(tmp_path)
+    feats = [torch.tensor(g[f"feat{b}"]) for b in range(3)]
+    sups = [(g[f"coords{b}"], g[f"values{b}"], tuple(int(x) for x in g[f"shape{b}"])) for b in range(3)]
+    vf = [torch.tensor(g[f"vfeat{b}"]) for b in range(2)]
+    vs = [(g[f"vcoords{b}"], g[f"vvalues{b}"], tuple(int(x) for x in g[f"vshape{b}"])) for b in range(2)]
+    cfg = {"dataset": "facade", "n_clusters": 6, "should_use_ae": True, "should_use_siamese": False,
+           "ae": dict(AE_CFG["ae"], epochs=2),
+           "spectral": {"architecture": {"n_layers": 4, "hidden_dim1": 32, "hidden_dim2": 32, "hidden_dim3": 16, "output_dim": 6},
+                        "epochs": 2, "lr": 1e-3, "lr_decay": 0.1, "min_lr": 1e-7, "batch_size": 1024, "n_clusters": 6,
+                        "patience": 10, "bsize": 1}}
+    torch.manual_seed(0)
+    np.random.seed(0)
+    net = SpectralNet(n_clusters=6, config=cfg)
+    net.fit(([np.arange(f.shape[0]) for f in feats], feats, sups, [None] * 3, [None] * 3),
+            (list(range(2)), vf, vs, [None] * 2, [None] * 2))
+    out = capsys.readouterr().out
+    assert "Training Autoencoder:" in out and "Training SpectralNet:" in out
+    X = torch.cat(feats + vf, dim=0)
+    Y = net.predict(X, chunk_rows=128)
+    E = net.embed(X)
+    assert Y.shape == (X.shape[0], 6) and E.shape == (X.shape[0], 5) and np.isfinite(Y).all()
+    # the embedding of the orthonormalisation batch is orthonormal up to the weights' batch: finite and non-trivial
+    assert np.abs(Y).max() > 0
+    # predict = MLP(encoder(X)) @ orthonormalisation weights
+    with torch.no_grad():
+        code = net.ae_net.encode(X.to(dev))
+        want = net.spec_net(code, should_update_orth_weights=False).cpu().numpy()
+    assert rel(Y, want) < 1e-5 and rel(E, code.cpu().numpy()) < 1e-6
+    save_results(str(tmp_path / "sparc_results" / "facade"), Y, X, np.zeros(len(X), int), np.ones(len(X), bool),
+                 np.ones(len(X), bool), np.ones(len(X), bool), E)
+    assert np.allclose(np.load(tmp_path / "sparc_results" / "facade" / "embeddings.npy"), Y / np.sqrt(len(X)))
