@@ -146,7 +146,7 @@ def main():
     if world > 1:
         dist.barrier()
     # HIP events around the inner row-gather passes (epilogue 1), on the launch stream
-    check(lib.sparc_profile_begin(1, 2 * args.steps), "sparc_profile_begin")
+    check(lib.sparc_profile_begin(1, args.steps), "sparc_profile_begin")   # one event pair per step: both inner passes
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     nodes = 0

@@ -124,8 +124,9 @@ int sparc_spmm(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* col
 /* Measurement aid (no counterpart in the reference): between begin and end, every launch of the
  * row-gather kernel with the given epilogue (1 = the two inner passes of sparc_lap_fwd and
  * sparc_spmm with X0, 0 = sparc_spmm without X0, 4 / 3 = the last pass with / without gradient)
- * is bracketed by HIP events on its stream, up to max_launches.  sparc_profile_end waits for them
- * and returns the summed elapsed milliseconds and the number of launches timed (host pointers).
+ * is bracketed by HIP events on its stream, up to max_launches event pairs (the two inner passes of one
+ * sparc_lap_fwd call share a pair).  sparc_profile_end waits for them and returns the summed elapsed
+ * milliseconds and the number of kernel launches they cover (host pointers).
  * Not thread-safe; allocates and frees the events in begin / end, never in a launch path. */
 int sparc_profile_begin(int epilogue, int max_launches);
 int sparc_profile_end(double* total_ms, int64_t* launches);
