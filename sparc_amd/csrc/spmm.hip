@@ -300,35 +300,98 @@ __device__ __forceinline__ Chunk load_chunk(const SpmmArgs& a, const int lo, con
     return ck;
 }
 
-template <bool DUAL, int U>
-__device__ __forceinline__ void tile_step(float4& acc, const Chunk& ck, const bool right, const int lr16,
-                                          const char* __restrict__ tile_bytes) {
-    const int addr = row_bcast<U>(ck.addr) + lr16;
-    float w = row_bcastf<U>(ck.v);
-    if (DUAL) {
-        const float wt = row_bcastf<U>(ck.vt);
-        w = right ? wt : w;
-    }
-    const float4 x = *reinterpret_cast<const float4*>(tile_bytes + addr);
-    acc.x = fmaf(w, x.x, acc.x);
-    acc.y = fmaf(w, x.y, acc.y);
-    acc.z = fmaf(w, x.z, acc.z);
-    acc.w = fmaf(w, x.w, acc.w);
+// One entry of each of the wave's four rows.  The broadcasts are folded into the instructions that use
+// them: the LDS address is one v_add_u32 with a DPP source (lane U of the row + this lane's column
+// offset), and in the training pass the weight is two DPP moves into one register, val into the lanes
+// of the A half (DPP banks 0-1) and valT into the lanes of the A^T half (banks 2-3): no select.
+typedef float lds_vec4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const lds_vec4 lds_float4;
+
+template <int U>
+__device__ __forceinline__ int step_addr(const Chunk& ck, const int lane_base) {
+    int addr;  // lane U's row offset + this lane's column offset + the window's LDS base: an absolute LDS address
+    asm("v_add_u32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(addr) : "v"(ck.addr), "v"(lane_base), "n"(U));
+    return addr;
 }
 
-// `steps` (1..16, wave-uniform, in an SGPR) entries of the chunk
-template <bool DUAL>
-__device__ __forceinline__ void tile_chunk(float4& acc, const Chunk& ck, const int steps, const bool right,
-                                           const int lr16, const char* __restrict__ tile_bytes) {
-#define SPARC_STEP4(U)                                       \
-    if (steps > U) {                                         \
-        tile_step<DUAL, U>(acc, ck, right, lr16, tile_bytes);     \
-        tile_step<DUAL, U + 1>(acc, ck, right, lr16, tile_bytes); \
-        tile_step<DUAL, U + 2>(acc, ck, right, lr16, tile_bytes); \
-        tile_step<DUAL, U + 3>(acc, ck, right, lr16, tile_bytes); \
+template <bool DUAL, int U>
+__device__ __forceinline__ float step_weight(const Chunk& ck) {
+    float w;
+    if (DUAL) {
+        asm("v_mov_b32_dpp %0, %1 row_newbcast:%3 row_mask:0xf bank_mask:0x3\n\t"
+            "v_mov_b32_dpp %0, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xc"
+            : "=&v"(w)
+            : "v"(ck.v), "v"(ck.vt), "n"(U));
+    } else {
+        w = row_bcastf<U>(ck.v);
     }
-    SPARC_STEP4(0) SPARC_STEP4(4) SPARC_STEP4(8) SPARC_STEP4(12)
-#undef SPARC_STEP4
+    return w;
+}
+
+__device__ __forceinline__ void step_fma(float4& acc, const float w, const lds_vec4 x) {
+    acc.x = fmaf(w, x[0], acc.x);
+    acc.y = fmaf(w, x[1], acc.y);
+    acc.z = fmaf(w, x[2], acc.z);
+    acc.w = fmaf(w, x[3], acc.w);
+}
+
+// Four entries of each of the wave's four rows.  The broadcasts are folded into the instructions that
+// use them: the LDS address is one v_add_u32 with a DPP source, and in the training pass the weight is
+// two DPP moves into one register, val into the lanes of the A half (DPP banks 0-1) and valT into the
+// lanes of the A^T half (banks 2-3): no select.  The four LDS reads are requested together and the
+// products alternate between two accumulators.
+template <bool DUAL, int U>
+__device__ __forceinline__ void tile_step4(float4& acc0, float4& acc1, const Chunk& ck, const int lane_base) {
+    const int a0 = step_addr<U>(ck, lane_base), a1 = step_addr<U + 1>(ck, lane_base);
+    const int a2 = step_addr<U + 2>(ck, lane_base), a3 = step_addr<U + 3>(ck, lane_base);
+    const lds_vec4 x0 = *(lds_float4*)(unsigned long)(unsigned)a0;
+    const lds_vec4 x1 = *(lds_float4*)(unsigned long)(unsigned)a1;
+    const lds_vec4 x2 = *(lds_float4*)(unsigned long)(unsigned)a2;
+    const lds_vec4 x3 = *(lds_float4*)(unsigned long)(unsigned)a3;
+    const float w0 = step_weight<DUAL, U>(ck), w1 = step_weight<DUAL, U + 1>(ck);
+    const float w2 = step_weight<DUAL, U + 2>(ck), w3 = step_weight<DUAL, U + 3>(ck);
+    step_fma(acc0, w0, x0);
+    step_fma(acc1, w1, x1);
+    step_fma(acc0, w2, x2);
+    step_fma(acc1, w3, x3);
+}
+
+// The same with two reads in flight and one accumulator: for the epilogues that leave few registers.
+template <bool DUAL, int U>
+__device__ __forceinline__ void tile_step2x2(float4& acc, const Chunk& ck, const int lane_base) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int a0 = h ? step_addr<U + 2>(ck, lane_base) : step_addr<U>(ck, lane_base);
+        const int a1 = h ? step_addr<U + 3>(ck, lane_base) : step_addr<U + 1>(ck, lane_base);
+        const lds_vec4 x0 = *(lds_float4*)(unsigned long)(unsigned)a0;
+        const lds_vec4 x1 = *(lds_float4*)(unsigned long)(unsigned)a1;
+        const float w0 = h ? step_weight<DUAL, U + 2>(ck) : step_weight<DUAL, U>(ck);
+        const float w1 = h ? step_weight<DUAL, U + 3>(ck) : step_weight<DUAL, U + 1>(ck);
+        step_fma(acc, w0, x0);
+        step_fma(acc, w1, x1);
+    }
+}
+
+// `steps` (1..16, wave-uniform, in an SGPR) entries of the chunk, four at a time (idle steps carry a
+// zero weight); lane_base = this lane's column offset inside a window row + the window's LDS base
+template <bool DUAL, bool WIDE>
+__device__ __forceinline__ void tile_chunk(float4& acc, const Chunk& ck, const int steps, const int lane_base) {
+    if (WIDE) {
+        float4 acc1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (steps > 0) tile_step4<DUAL, 0>(acc, acc1, ck, lane_base);
+        if (steps > 4) tile_step4<DUAL, 4>(acc, acc1, ck, lane_base);
+        if (steps > 8) tile_step4<DUAL, 8>(acc, acc1, ck, lane_base);
+        if (steps > 12) tile_step4<DUAL, 12>(acc, acc1, ck, lane_base);
+        acc.x += acc1.x;
+        acc.y += acc1.y;
+        acc.z += acc1.z;
+        acc.w += acc1.w;
+    } else {
+        if (steps > 0) tile_step2x2<DUAL, 0>(acc, ck, lane_base);
+        if (steps > 4) tile_step2x2<DUAL, 4>(acc, ck, lane_base);
+        if (steps > 8) tile_step2x2<DUAL, 8>(acc, ck, lane_base);
+        if (steps > 12) tile_step2x2<DUAL, 12>(acc, ck, lane_base);
+    }
 }
 
 template <bool DUAL, int EPI>
@@ -391,7 +454,9 @@ __global__ __launch_bounds__(TILED_THREADS) void spmm_tiled(const SpmmArgs a) {
     for (int i = threadIdx.x; i < nq * 3; i += TILED_THREADS)
         info[i] = reinterpret_cast<const int4*>(a.rowinfo)[static_cast<int64_t>(q_begin) * 3 + i];
     const char* tile_bytes = reinterpret_cast<const char*>(tile);
-    const int lr16 = lr * 16;
+    constexpr bool WIDE = EPI != EPI_LAP_SINGLE && EPI != EPI_LAP_DUAL;   // the loss epilogues leave fewer registers
+    // this lane's column offset inside a window row plus the window's LDS base address
+    const int lr16 = lr * 16 + (int)(unsigned long)(__attribute__((address_space(3))) const char*)tile_bytes;
     const LapConst lc = lap_const<EPI>(a, kp, cl, right);
     __syncthreads();  // the window and the records have landed (the barrier waits for the LDS copies)
 
@@ -457,11 +522,11 @@ __global__ __launch_bounds__(TILED_THREADS) void spmm_tiled(const SpmmArgs a) {
         acc.y = fmaf(cur.ow1, cur.ox1.y, cur.ow0 * cur.ox0.y);
         acc.z = fmaf(cur.ow1, cur.ox1.z, cur.ow0 * cur.ox0.z);
         acc.w = fmaf(cur.ow1, cur.ox1.w, cur.ow0 * cur.ox0.w);
-        if (steps > 0) tile_chunk<DUAL>(acc, cur.c0, min(steps, 16), right, lr16, tile_bytes);
-        if (steps > 16) tile_chunk<DUAL>(acc, cur.c1, min(steps - 16, 16), right, lr16, tile_bytes);
+        if (steps > 0) tile_chunk<DUAL, WIDE>(acc, cur.c0, min(steps, 16), lr16);
+        if (steps > 16) tile_chunk<DUAL, WIDE>(acc, cur.c1, min(steps - 16, 16), lr16);
         for (int c = 2; c * 16 < steps; ++c) {
             const Chunk ck = load_chunk<DUAL>(a, ri.y, ri.z, c * cstride, off, w0, 0);
-            tile_chunk<DUAL>(acc, ck, min(steps - c * 16, 16), right, lr16, tile_bytes);
+            tile_chunk<DUAL, WIDE>(acc, ck, min(steps - c * 16, 16), lr16);
         }
         if (lng) {  // merge the four DPP rows
             acc.x += __shfl_xor(acc.x, 16); acc.y += __shfl_xor(acc.y, 16);
