@@ -106,7 +106,9 @@ int sparc_lap_fwd(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* 
  * share a wavefront four at a time and the first of the four bounds its trip count: it MUST be
  * the longest of the four.  Rows
  * with more outside entries belong to workgroups with slab = -1, which gather the rows of their
- * records whole from global memory.  Every (row, slab) pair must be produced exactly once.  A
+ * records whole from global memory.  Every (row, slab) pair must be produced exactly once; a descriptor with q_begin == q_end is an empty
+ * workgroup (padding that lets a caller place the workgroups of one window on one XCD: workgroup b runs
+ * on XCD b % 8).  A
  * slab is 32 columns of each half for the training pass (slab < kp/32, kp = k rounded up to
  * 16/32/64; used when kp >= 32) or all 64 columns for the forward-only pass (slab = 0; used when
  * kp == 64).  tile_rows = the largest window, at most SPARC_TILE_MAX_ROWS; nnz < 2^31. */

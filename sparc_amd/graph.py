@@ -96,9 +96,41 @@ def plan_tiles(windows, lo: np.ndarray, hi: np.ndarray, n_out: np.ndarray, out_r
                 recs.append(records(part))
                 desc.append((q, q + len(part), 0, 0, -1, 0, 0, 0))
                 q += len(part)
-    desc = np.asarray(desc, dtype=np.int32).reshape(-1, 8)
+    desc = np.asarray(_xcd_align(desc), dtype=np.int32).reshape(-1, 8)
     recs = np.concatenate(recs, axis=0).astype(np.int32) if recs else np.zeros((0, 12), np.int32)
     return desc, recs
+
+
+N_XCD = 8  # workgroup b runs on XCD b % 8 (round-robin dispatch), and every XCD has its own L2
+
+
+def _xcd_align(desc):
+    """Order the descriptors so that all workgroups of one window run on the same XCD: the parts of a
+    window stage the same operand rows and its slabs stream the same stored entries, so the second
+    reader finds them in that XCD's L2 instead of fetching them again.  Windows are dealt to eight
+    bins (heaviest first, to the lightest bin); bin x supplies the descriptors at positions x, x + 8, ...;
+    shorter bins are padded with empty descriptors (a workgroup that finds no rows and returns)."""
+    if len(desc) <= N_XCD:
+        return desc
+    groups = {}
+    for d in desc:
+        key = (d[2], d[3]) if d[4] >= 0 else ("loose", d[0])
+        groups.setdefault(key, []).append(d)
+    bins = [[] for _ in range(N_XCD)]
+    load = [0] * N_XCD
+    for key, ds in sorted(groups.items(), key=lambda kv: -sum(d[1] - d[0] for d in kv[1])):
+        x = min(range(N_XCD), key=lambda i: (load[i], len(bins[i])))
+        bins[x].extend(ds)
+        load[x] += sum(d[1] - d[0] for d in ds)
+    depth = max(len(b) for b in bins)
+    empty = (0, 0, 0, 0, 0, 0, 0, 0)
+    out = []
+    for r in range(depth):
+        for x in range(N_XCD):
+            out.append(bins[x][r] if r < len(bins[x]) else empty)
+    while out and out[-1] == empty:
+        out.pop()
+    return out
 
 
 def _ptr(t):
