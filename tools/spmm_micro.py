@@ -17,7 +17,7 @@ dev = torch.device("cuda:0")
 scale = float(os.environ.get("SCALE", "1.0"))
 n = int(2449029 * scale)
 graph, bounds = synth.planted_cluster_graph(n, int(61859140 * scale), int(5000 * scale), dev, seed=0)
-nodes_of, cids = synth.cluster_batches(bounds, 50, seed=0, return_clusters=True)
+nodes_of, cids = synth.cluster_batches(bounds, int(os.environ.get("BSIZE", "50")), seed=0, return_clusters=True)
 pt = nodes_of[0]
 coords, values, shp, _ = graph.subblock(pt, mode=2, binarize=False, diag_lambda=0.01)
 csz = np.diff(bounds.cpu().numpy())[cids[0]]
@@ -36,4 +36,5 @@ for tiles in (True, False):
     for _ in range(reps):
         b.lap(Y, True)
     torch.cuda.synchronize()
-    print(f"tiles={tiles} m={b.m} nnz={b.nnz} lap_fwd(dual) {1e6 * (time.perf_counter() - t0) / reps:.1f} us/call", flush=True)
+    alg = b.nnz * 12 + (b.m + 1) * 8 + 3 * b.m * 128 * 4
+    print(f"tiles={tiles} m={b.m} nnz={b.nnz} algorithmic bytes per inner pass {alg} lap_fwd(dual) {1e6 * (time.perf_counter() - t0) / reps:.1f} us/call", flush=True)
