@@ -1,6 +1,7 @@
-"""torch.autograd glue around the HIP kernels of the orthonormalisation layer and the
-spectral loss.  torch supplies device memory, the stream and the autograd tape only;
-every numerical operation here runs in libsparc_hip.so.
+"""torch.autograd glue around the HIP kernels: the MLP, the orthonormalisation layer and the
+spectral loss.  torch supplies device memory, the stream, the autograd tape and the wide
+dense products of the MLP (library GEMMs); every other numerical operation here runs in
+libsparc_hip.so.
 """
 from __future__ import annotations
 
