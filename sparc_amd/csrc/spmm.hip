@@ -476,31 +476,38 @@ __global__ __launch_bounds__(TILED_THREADS) void spmm_tiled(const SpmmArgs a) {
     // are merged at the end); the other records are taken four at a time, one row per DPP row.
     const int n_long = d[5];
     const int nslots = (a.dbg & 1) ? 0 : n_long + (nq - n_long + 3) / 4;
+    // The loss epilogues need many registers: for them (LEAN) a slot only carries the row record and the
+    // entry chunks ahead of time; the epilogue operands and the outside operands are requested at the
+    // start of the slot's own round and arrive behind its LDS gather.
+    constexpr bool LEAN = !WIDE;
+    auto fetch_operands = [&](Slot& s, const int slot) {
+        const bool lng = slot < n_long;
+        const int qi = lng ? slot : n_long + (slot - n_long) * 4 + g;
+        s.ow0 = s.ow1 = 0.f;
+        s.ox0 = s.ox1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s.ri.x >= 0 && s.ri.w > 0 && (!lng || g == 0)) {
+            const int4 o0 = info[qi * 3 + 1];
+            s.ow0 = __int_as_float(right ? o0.w : o0.z);
+            s.ox0 = *reinterpret_cast<const float4*>(a.Xg + static_cast<int64_t>(o0.x) * wtot + gcol);
+            if (s.ri.w > 1) {
+                const int4 o1 = info[qi * 3 + 2];
+                s.ow1 = __int_as_float(right ? o1.y : o1.x);
+                s.ox1 = *reinterpret_cast<const float4*>(a.Xg + static_cast<int64_t>(o0.y) * wtot + gcol);
+            }
+        }
+        s.pre = row_preload<EPI_STORE>(a, 0, 0, 0);
+        if (s.ri.x >= 0) s.pre = row_preload<EPI>(a, s.ri.x, wtot, gcol);
+    };
     auto fetch = [&](const int slot) {
         Slot s;
         const bool lng = slot < n_long;
         const int qi = lng ? slot : n_long + (slot - n_long) * 4 + g;
         s.ri = make_int4(-1, 0, 0, 0);
-        s.ow0 = s.ow1 = 0.f;
-        s.ox0 = s.ox1 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (slot < nslots && qi < nq) {
-            s.ri = info[qi * 3];
-            if (s.ri.w > 0 && (!lng || g == 0)) {
-                const int4 o0 = info[qi * 3 + 1];
-                s.ow0 = __int_as_float(right ? o0.w : o0.z);
-                s.ox0 = *reinterpret_cast<const float4*>(a.Xg + static_cast<int64_t>(o0.x) * wtot + gcol);
-                if (s.ri.w > 1) {
-                    const int4 o1 = info[qi * 3 + 2];
-                    s.ow1 = __int_as_float(right ? o1.y : o1.x);
-                    s.ox1 = *reinterpret_cast<const float4*>(a.Xg + static_cast<int64_t>(o0.y) * wtot + gcol);
-                }
-            }
-        }
+        if (slot < nslots && qi < nq) s.ri = info[qi * 3];
         const int off = lng ? lr * 4 + g : lr;  // entry of this lane inside a chunk
         s.c0 = load_chunk<DUAL>(a, s.ri.y, s.ri.z, 0, off, w0, 0);
         s.c1 = load_chunk<DUAL>(a, s.ri.y, s.ri.z, lng ? 64 : 16, off, w0, 0);
-        s.pre = row_preload<EPI_STORE>(a, 0, 0, 0);
-        if (s.ri.x >= 0) s.pre = row_preload<EPI>(a, s.ri.x, wtot, gcol);
+        if (!LEAN) fetch_operands(s, slot);
         return s;
     };
     // slots are sorted by work, longest first, and dealt to the waves in serpentine order
@@ -517,17 +524,19 @@ __global__ __launch_bounds__(TILED_THREADS) void spmm_tiled(const SpmmArgs a) {
         const int steps = (a.dbg & 2) ? 0 : (lng ? (nmax + 3) >> 2 : nmax);
         const int cstride = lng ? 64 : 16;  // entries per chunk
         const int off = lng ? lr * 4 + g : lr;
-        float4 acc;  // starts from the (at most two) entries outside the window
-        acc.x = fmaf(cur.ow1, cur.ox1.x, cur.ow0 * cur.ox0.x);
-        acc.y = fmaf(cur.ow1, cur.ox1.y, cur.ow0 * cur.ox0.y);
-        acc.z = fmaf(cur.ow1, cur.ox1.z, cur.ow0 * cur.ox0.z);
-        acc.w = fmaf(cur.ow1, cur.ox1.w, cur.ow0 * cur.ox0.w);
+        if (LEAN) fetch_operands(cur, slot_of(round));
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (steps > 0) tile_chunk<DUAL, WIDE>(acc, cur.c0, min(steps, 16), lr16);
         if (steps > 16) tile_chunk<DUAL, WIDE>(acc, cur.c1, min(steps - 16, 16), lr16);
         for (int c = 2; c * 16 < steps; ++c) {
             const Chunk ck = load_chunk<DUAL>(a, ri.y, ri.z, c * cstride, off, w0, 0);
             tile_chunk<DUAL, WIDE>(acc, ck, min(steps - c * 16, 16), lr16);
         }
+        // the (at most two) entries outside the window
+        acc.x += fmaf(cur.ow1, cur.ox1.x, cur.ow0 * cur.ox0.x);
+        acc.y += fmaf(cur.ow1, cur.ox1.y, cur.ow0 * cur.ox0.y);
+        acc.z += fmaf(cur.ow1, cur.ox1.z, cur.ow0 * cur.ox0.z);
+        acc.w += fmaf(cur.ow1, cur.ox1.w, cur.ow0 * cur.ox0.w);
         if (lng) {  // merge the four DPP rows
             acc.x += __shfl_xor(acc.x, 16); acc.y += __shfl_xor(acc.y, 16);
             acc.z += __shfl_xor(acc.z, 16); acc.w += __shfl_xor(acc.w, 16);
