@@ -476,10 +476,10 @@ __global__ __launch_bounds__(TILED_THREADS) void spmm_tiled(const SpmmArgs a) {
     // are merged at the end); the other records are taken four at a time, one row per DPP row.
     const int n_long = d[5];
     const int nslots = (a.dbg & 1) ? 0 : n_long + (nq - n_long + 3) / 4;
-    // The loss epilogues need many registers: for them (LEAN) a slot only carries the row record and the
-    // entry chunks ahead of time; the epilogue operands and the outside operands are requested at the
-    // start of the slot's own round and arrive behind its LDS gather.
-    constexpr bool LEAN = !WIDE;
+    // A slot only carries the row record and the entry chunks ahead of time; the epilogue operands and
+    // the outside operands are requested at the start of the slot's own round and arrive behind its LDS
+    // gather (carrying them two slots ahead as well costs registers: spills in the loss epilogues, and
+    // it measured slower for every epilogue).
     auto fetch_operands = [&](Slot& s, const int slot) {
         const bool lng = slot < n_long;
         const int qi = lng ? slot : n_long + (slot - n_long) * 4 + g;
@@ -507,7 +507,6 @@ __global__ __launch_bounds__(TILED_THREADS) void spmm_tiled(const SpmmArgs a) {
         const int off = lng ? lr * 4 + g : lr;  // entry of this lane inside a chunk
         s.c0 = load_chunk<DUAL>(a, s.ri.y, s.ri.z, 0, off, w0, 0);
         s.c1 = load_chunk<DUAL>(a, s.ri.y, s.ri.z, lng ? 64 : 16, off, w0, 0);
-        if (!LEAN) fetch_operands(s, slot);
         return s;
     };
     // slots are sorted by work, longest first, and dealt to the waves in serpentine order
@@ -524,7 +523,7 @@ __global__ __launch_bounds__(TILED_THREADS) void spmm_tiled(const SpmmArgs a) {
         const int steps = (a.dbg & 2) ? 0 : (lng ? (nmax + 3) >> 2 : nmax);
         const int cstride = lng ? 64 : 16;  // entries per chunk
         const int off = lng ? lr * 4 + g : lr;
-        if (LEAN) fetch_operands(cur, slot_of(round));
+        fetch_operands(cur, slot_of(round));
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (steps > 0) tile_chunk<DUAL, WIDE>(acc, cur.c0, min(steps, 16), lr16);
         if (steps > 16) tile_chunk<DUAL, WIDE>(acc, cur.c1, min(steps - 16, 16), lr16);
