@@ -435,6 +435,23 @@ __global__ __launch_bounds__(TILED_THREADS) void spmm_tiled(const SpmmArgs a) {
     const int cl = DUAL ? slab * 32 + (lr & 7) * 4 : slab * 64 + lr * 4;
     const int gcol = (right ? kp : 0) + cl;
 
+    // The records of this wave's first two slots are requested from global memory before anything else, so
+    // that their entry chunks can be requested while the window is still being staged (every later slot
+    // reads its record from the LDS copy made below).
+    const int nq = q_end - q_begin;
+    const int n_long = d[5];
+    const int nslots = (a.dbg & 1) ? 0 : n_long + (nq - n_long + 3) / 4;
+    auto slot_of = [&](const int round) { return round * TILED_WAVES + ((round & 1) ? TILED_WAVES - 1 - wave : wave); };
+    auto record_index = [&](const int slot) { return slot < n_long ? slot : n_long + (slot - n_long) * 4 + g; };
+    int4 early_ri[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int slot = slot_of(e), qi = record_index(slot);
+        early_ri[e] = make_int4(-1, 0, 0, 0);
+        if (slot < nslots && qi < nq)
+            early_ri[e] = reinterpret_cast<const int4*>(a.rowinfo)[(static_cast<int64_t>(q_begin) + qi) * 3];
+    }
+
     {   // stage the window with asynchronous global->LDS copies (no register round trip): one wave
         // instruction moves 64 x 16 bytes to LDS base + lane * 16, the source address is per lane
         const float* src = a.Xg + static_cast<int64_t>(w0) * wtot + gcol;
@@ -450,7 +467,6 @@ __global__ __launch_bounds__(TILED_THREADS) void spmm_tiled(const SpmmArgs a) {
     // the row records of this workgroup, in LDS: 3 x int4 per row =
     // {row, lo, hi, n_outside}, {col0, col1, val0, valT0}, {val1, valT1, 0, 0}
     __shared__ int4 info[SPARC_TILE_MAX_ROWS * 3];
-    const int nq = q_end - q_begin;
     for (int i = threadIdx.x; i < nq * 3; i += TILED_THREADS)
         info[i] = reinterpret_cast<const int4*>(a.rowinfo)[static_cast<int64_t>(q_begin) * 3 + i];
     const char* tile_bytes = reinterpret_cast<const char*>(tile);
@@ -458,12 +474,12 @@ __global__ __launch_bounds__(TILED_THREADS) void spmm_tiled(const SpmmArgs a) {
     // this lane's column offset inside a window row plus the window's LDS base address
     const int lr16 = lr * 16 + (int)(unsigned long)(__attribute__((address_space(3))) const char*)tile_bytes;
     const LapConst lc = lap_const<EPI>(a, kp, cl, right);
-    __syncthreads();  // the window and the records have landed (the barrier waits for the LDS copies)
-
-    // A wave owns slots wave, wave + 16, ... (4 rows each).  The entries and epilogue operands of a
-    // slot are requested two slots ahead: global-memory latency hides behind two slots of LDS work.
-    // Up to two entries of a row may lie outside the window; their columns and values travel in the
-    // row record, so their operand rows are requested from global memory with the same prefetch.
+    // A wave owns slots wave, wave + 16, ... (4 rows each), sorted by work (longest first) and dealt in
+    // serpentine order.  Slots: the first n_long records are long rows (more than SPARC_TILE_LONG_ROW
+    // in-window entries), each worked on by the whole wave (DPP row g takes entries g, g + 4, ...; the four
+    // partial sums are merged at the end); the other records are taken four at a time, one row per DPP row.
+    // Up to two entries of a row may lie outside the window; their columns and values travel in the row
+    // record and their operand rows come from global memory.
     struct Slot {
         int4 ri;
         Chunk c0, c1;
@@ -471,18 +487,26 @@ __global__ __launch_bounds__(TILED_THREADS) void spmm_tiled(const SpmmArgs a) {
         float ow0, ow1;
         float4 ox0, ox1;
     };
-    // Slots: the first n_long records are long rows (more than SPARC_TILE_LONG_ROW in-window entries),
-    // each worked on by the whole wave (DPP row g takes entries g, g + 4, ...; the four partial sums
-    // are merged at the end); the other records are taken four at a time, one row per DPP row.
-    const int n_long = d[5];
-    const int nslots = (a.dbg & 1) ? 0 : n_long + (nq - n_long + 3) / 4;
-    // A slot only carries the row record and the entry chunks ahead of time; the epilogue operands and
-    // the outside operands are requested at the start of the slot's own round and arrive behind its LDS
-    // gather (carrying them two slots ahead as well costs registers: spills in the loss epilogues, and
-    // it measured slower for every epilogue).
+    // The entry chunks of a slot are requested two slots ahead: global-memory latency hides behind two
+    // slots of LDS work (for the first two slots: behind the staging of the window).
+    auto with_chunks = [&](const int4 ri, const int slot) {
+        Slot s;
+        const bool lng = slot < n_long;
+        s.ri = ri;
+        const int off = lng ? lr * 4 + g : lr;  // entry of this lane inside a chunk
+        s.c0 = load_chunk<DUAL>(a, s.ri.y, s.ri.z, 0, off, w0, 0);
+        s.c1 = load_chunk<DUAL>(a, s.ri.y, s.ri.z, lng ? 64 : 16, off, w0, 0);
+        return s;
+    };
+    Slot cur = with_chunks(early_ri[0], slot_of(0)), nxt = with_chunks(early_ri[1], slot_of(1));
+    __syncthreads();  // the window and the records have landed (the barrier waits for the LDS copies)
+
+    // The epilogue operands and the outside operands of a slot are requested at the start of the slot's own
+    // round and arrive behind its LDS gather (carrying them two slots ahead as well costs registers: spills
+    // in the loss epilogues, and it measured slower for every epilogue).
     auto fetch_operands = [&](Slot& s, const int slot) {
         const bool lng = slot < n_long;
-        const int qi = lng ? slot : n_long + (slot - n_long) * 4 + g;
+        const int qi = record_index(slot);
         s.ow0 = s.ow1 = 0.f;
         s.ox0 = s.ox1 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (s.ri.x >= 0 && s.ri.w > 0 && (!lng || g == 0)) {
@@ -499,19 +523,11 @@ __global__ __launch_bounds__(TILED_THREADS) void spmm_tiled(const SpmmArgs a) {
         if (s.ri.x >= 0) s.pre = row_preload<EPI>(a, s.ri.x, wtot, gcol);
     };
     auto fetch = [&](const int slot) {
-        Slot s;
-        const bool lng = slot < n_long;
-        const int qi = lng ? slot : n_long + (slot - n_long) * 4 + g;
-        s.ri = make_int4(-1, 0, 0, 0);
-        if (slot < nslots && qi < nq) s.ri = info[qi * 3];
-        const int off = lng ? lr * 4 + g : lr;  // entry of this lane inside a chunk
-        s.c0 = load_chunk<DUAL>(a, s.ri.y, s.ri.z, 0, off, w0, 0);
-        s.c1 = load_chunk<DUAL>(a, s.ri.y, s.ri.z, lng ? 64 : 16, off, w0, 0);
-        return s;
+        const int qi = record_index(slot);
+        int4 ri = make_int4(-1, 0, 0, 0);
+        if (slot < nslots && qi < nq) ri = info[qi * 3];
+        return with_chunks(ri, slot);
     };
-    // slots are sorted by work, longest first, and dealt to the waves in serpentine order
-    auto slot_of = [&](const int round) { return round * TILED_WAVES + ((round & 1) ? TILED_WAVES - 1 - wave : wave); };
-    Slot cur = fetch(slot_of(0)), nxt = fetch(slot_of(1));
 
     double wloss = 0.0;
     for (int round = 0; round * TILED_WAVES < nslots; ++round) {  // wave-uniform
