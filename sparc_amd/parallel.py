@@ -1,6 +1,6 @@
 """Cluster batches sharded over the GPUs of one node: one process per GPU, the MLP
 replicated, every rank training on its own batches, and one collective per step, the
-all-reduce of the flat MLP gradient (RCCL over xGMI through torch.distributed).
+all-reduce of the MLP gradient packed into one bucket (RCCL over xGMI through torch.distributed).
 
 The reference is single-device (src/SpectralNet.py:21); its batches are independent
 units (each support is the induced sub-block of its own nodes, src/utils.py:83), which
@@ -47,29 +47,25 @@ def shard_batches(n_batches: int, world_size: int, rank: int) -> List[int]:
     return list(range(rank, n_batches, world_size))
 
 
-class FlatGradients:
-    """All parameter gradients as views into one contiguous buffer, so that the per-step
-    collective is a single all-reduce over one bucket (6-8 MB for the SpectralNet MLP)."""
-
-    def __init__(self, params: Sequence[torch.nn.Parameter]):
-        self.params = [p for p in params if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
-        ref = self.params[0]
-        self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
-        off = 0
-        for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
-
-    def zero(self):
-        self.flat.zero_()
-
-    def all_reduce_mean(self, group=None):
-        if dist.is_available() and dist.is_initialized():
-            ws = dist.get_world_size(group)
-            if ws > 1:
-                all_reduce_sum(self.flat, group)
-                self.flat.div_(ws)
+def all_reduce_mean_gradients(params: Sequence[torch.nn.Parameter], group=None) -> Optional[torch.Tensor]:
+    """Average the gradients autograd left in .grad over the ranks with ONE collective: they are packed
+    into one bucket (a single copy), reduced, and every .grad becomes a view into the bucket.  Compared
+    with gradients that live in a persistent flat buffer this needs no zero-fill and no accumulation
+    kernel per parameter.  A no-op without a process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) < 2:
+        return None
+    owners = [p for p in params if p.grad is not None]
+    if not owners:
+        return None
+    flat = torch.cat([p.grad.reshape(-1) for p in owners])
+    all_reduce_sum(flat, group)
+    flat.div_(dist.get_world_size(group))
+    off = 0
+    for p in owners:
+        n = p.numel()
+        p.grad = flat[off:off + n].view_as(p)
+        off += n
+    return flat
 
 
 class ShardedSpectralTrainer:
@@ -87,7 +83,7 @@ class ShardedSpectralTrainer:
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             for p in self.net.parameters():
                 broadcast(p.data, 0, group)
-        self.grads = FlatGradients(list(self.net.parameters()))
+        self.params = list(self.net.parameters())
         self.optimizer = torch.optim.Adam(self.net.parameters(), lr=lr, fused=True)
         self.criterion = SpectralNetLoss()
         self.features = []
@@ -103,11 +99,11 @@ class ShardedSpectralTrainer:
         (src/SpectralTrainer.py:216-238), gradient averaged over the ranks before Adam."""
         net = self.net
         net.train()
-        self.grads.zero()
+        self.optimizer.zero_grad(set_to_none=True)   # autograd hands its gradients over as they are: no accumulation
         Y = net.forward_pair(self.features[pid_2], self.features[pid], top_idx=top_idx)
         loss = self.criterion(self.batches[pid], Y, is_normalized=True)
         loss.backward()
-        self.grads.all_reduce_mean(self.group)
+        all_reduce_mean_gradients(self.params, self.group)   # one bucket, one collective (nothing on a single rank)
         self.optimizer.step()
         return loss.detach()
 
