@@ -117,11 +117,14 @@ int sparc_lap_fwd(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* 
 #define SPARC_TILE_LONG_ROW 64
 
 /* Plain product Z = A X (+ X0 if X0 != NULL) on the same kernels, X, X0, Z [m][width] with
- * width in {16, 32, 64, 128} (tiles: width 64 only, slab 0).  Exposed for roofline
+ * width in {16, 32, 64, 128} (tiles: width 64 only, slab 0).  Passing the mirrored values as
+ * `val` gives A^T X; with tiles, val_is_mirrored != 0 then makes the kernel take the mirrored
+ * value of the entries repeated in the row records as well.  Exposed for roofline
  * measurements on whole graphs. */
 int sparc_spmm(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* colidx,
                const float* val, int width, const float* X, const float* X0, float* Z,
-               const int32_t* tiles, int ntiles, int tile_rows, sparc_stream_t stream);
+               const int32_t* tiles, int ntiles, int tile_rows, int val_is_mirrored,
+               sparc_stream_t stream);
 
 /* Measurement aid (no counterpart in the reference): between begin and end, every launch of the
  * row-gather kernel with the given epilogue (1 = the two inner passes of sparc_lap_fwd and

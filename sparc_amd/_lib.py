@@ -37,7 +37,7 @@ _SIGS = {
     "sparc_affinity_prep": (c_int, [c_int64, c_int64, P, P, P, P, c_double, P, P, P, P, c_size_t, P]),
     "sparc_lap_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "sparc_lap_fwd": (c_int, [c_int64, c_int64, P, P, P, P, P, P, c_int, c_int64, P, P, P, P, c_int, c_int, P, c_size_t, P]),
-    "sparc_spmm": (c_int, [c_int64, c_int64, P, P, P, c_int, P, P, P, P, c_int, c_int, P]),
+    "sparc_spmm": (c_int, [c_int64, c_int64, P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, P]),
     "sparc_profile_begin": (c_int, [c_int, c_int]),
     "sparc_profile_end": (c_int, [P, P]),
     "sparc_gram_workspace_bytes": (c_size_t, [c_int64, c_int]),

@@ -33,6 +33,7 @@ struct SpmmArgs {
     // over the row records rowinfo int32[m][12] (layout: include/sparc_hip.h)
     const int32_t* desc;
     const int32_t* rowinfo;
+    bool rec_mirrored;  // single-width tiled pass: `val` holds the mirrored values, so take valT of the records' outside entries
     int dbg;  // ablation switches for kernel timing experiments (0 in production)
     int ndesc;
     int tile_rows;  // largest window (rows) over all descriptors

@@ -309,23 +309,20 @@ typedef __attribute__((address_space(3))) const lds_vec4 lds_float4;
 
 template <int U>
 __device__ __forceinline__ int step_addr(const Chunk& ck, const int lane_base) {
-    int addr;  // lane U's row offset + this lane's column offset + the window's LDS base: an absolute LDS address
-    asm("v_add_u32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(addr) : "v"(ck.addr), "v"(lane_base), "n"(U));
-    return addr;
+    // lane U's row offset + this lane's column offset + the window's LDS base: an absolute LDS address.
+    // Compiler-visible DPP (folded into one v_add_u32_dpp), so that the VALU-write -> DPP-read wait states
+    // are inserted by the hazard recognizer.
+    return __builtin_amdgcn_update_dpp(0, ck.addr, 0x150 + U, 0xf, 0xf, false) + lane_base;
 }
 
 template <bool DUAL, int U>
 __device__ __forceinline__ float step_weight(const Chunk& ck) {
-    float w;
-    if (DUAL) {
-        asm("v_mov_b32_dpp %0, %1 row_newbcast:%3 row_mask:0xf bank_mask:0x3\n\t"
-            "v_mov_b32_dpp %0, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xc"
-            : "=&v"(w)
-            : "v"(ck.v), "v"(ck.vt), "n"(U));
-    } else {
-        w = row_bcastf<U>(ck.v);
+    if (DUAL) {  // val into DPP banks 0-1 (the A half), valT into banks 2-3 (the A^T half)
+        int w = __builtin_amdgcn_update_dpp(0, __float_as_int(ck.v), 0x150 + U, 0xf, 0x3, false);
+        w = __builtin_amdgcn_update_dpp(w, __float_as_int(ck.vt), 0x150 + U, 0xf, 0xc, false);
+        return __int_as_float(w);
     }
-    return w;
+    return row_bcastf<U>(ck.v);
 }
 
 __device__ __forceinline__ void step_fma(float4& acc, const float w, const lds_vec4 x) {
@@ -511,11 +508,12 @@ __global__ __launch_bounds__(TILED_THREADS) void spmm_tiled(const SpmmArgs a) {
         s.ox0 = s.ox1 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (s.ri.x >= 0 && s.ri.w > 0 && (!lng || g == 0)) {
             const int4 o0 = info[qi * 3 + 1];
-            s.ow0 = __int_as_float(right ? o0.w : o0.z);
+            const bool mirrored = right || a.rec_mirrored;   // which of the record's two values this lane multiplies by
+            s.ow0 = __int_as_float(mirrored ? o0.w : o0.z);
             s.ox0 = *reinterpret_cast<const float4*>(a.Xg + static_cast<int64_t>(o0.x) * wtot + gcol);
             if (s.ri.w > 1) {
                 const int4 o1 = info[qi * 3 + 2];
-                s.ow1 = __int_as_float(right ? o1.y : o1.x);
+                s.ow1 = __int_as_float(mirrored ? o1.y : o1.x);
                 s.ox1 = *reinterpret_cast<const float4*>(a.Xg + static_cast<int64_t>(o0.y) * wtot + gcol);
             }
         }
@@ -827,11 +825,12 @@ int set_tiles(SpmmArgs& a, const int32_t* tiles, int ntiles, int tile_rows, int 
 
 extern "C" int sparc_spmm(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* colidx, const float* val,
                           int width, const float* X, const float* X0, float* Z, const int32_t* tiles, int ntiles,
-                          int tile_rows, sparc_stream_t stream) {
+                          int tile_rows, int val_is_mirrored, sparc_stream_t stream) {
     if (m < 0 || nnz < 0 || !rowptr || (nnz > 0 && (!colidx || !val)) || !X || !Z) return SPARC_ERR_ARG;
     SpmmArgs a = {};
     a.m = m; a.rowptr = rowptr; a.col = colidx; a.val = val; a.valT = val;
     a.Xg = X; a.X0 = X0; a.out = Z;
+    a.rec_mirrored = val_is_mirrored != 0;
     if (tiles && width != 64) return SPARC_ERR_ARG;
     const int rc = set_tiles(a, tiles, ntiles, tile_rows, width, width);
     if (rc) return rc;

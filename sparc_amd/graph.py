@@ -307,6 +307,12 @@ class ClusterBatch:
                                           _ptr(ws), nbytes, _stream()), "sparc_affinity_prep")
         self.d, self.cw, self.rho = vec[0], vec[1], vec[2]
 
+    @staticmethod
+    def train_slabs(k: int) -> int:
+        """Column slabs of the tiled training pass for spectral dimension k (0: the row kernel runs)."""
+        kp = 16 if k <= 16 else (32 if k <= 32 else 64)
+        return kp // 32
+
     def warm(self, k: int, training: bool = True):
         """Build the tiling for spectral dimension k now (it is otherwise built on first use)."""
         kp = 16 if k <= 16 else (32 if k <= 32 else 64)
@@ -358,7 +364,8 @@ class ClusterBatch:
         tiles, ntiles, tile_rows = self.tiles(1) if tiled else (None, 0, 0)
         with torch.cuda.device(self.device):
             check(lib.sparc_spmm(self.m, self.nnz, _ptr(self.rowptr), _ptr(self.colidx), _ptr(v), int(X.shape[1]),
-                                 _ptr(X), _ptr(add), _ptr(Z), _ptr(tiles), ntiles, tile_rows, _stream()), "sparc_spmm")
+                                 _ptr(X), _ptr(add), _ptr(Z), _ptr(tiles), ntiles, tile_rows,
+                                 int(transpose and self.valT is not None), _stream()), "sparc_spmm")
         return Z
 
     def nbytes(self) -> int:

@@ -40,7 +40,7 @@ def test_workspace_queries_without_gpu():
 
 def test_bad_arguments_are_rejected_before_any_launch():
     from sparc_amd._lib import lib
-    assert lib.sparc_spmm(-1, 0, None, None, None, 64, None, None, None, None, 0, 0, None) == -1
+    assert lib.sparc_spmm(-1, 0, None, None, None, 64, None, None, None, None, 0, 0, 0, None) == -1
     assert lib.sparc_gram(10, 65, None, 65, None, 65, None, None, 0, None) == -1
     assert lib.sparc_orth_apply(0, 8, None, 8, None, 0, None, 8, None) == -1
 

@@ -64,7 +64,7 @@ def run(name, n, rowptr, colidx, width=64, reps=5):
     P = lambda t: ctypes.c_void_p(t.data_ptr())
 
     def launch():
-        check(lib.sparc_spmm(n, nnz, P(rowptr), P(colidx), P(val), width, P(X), None, P(Z), None, 0, 0, stream), "sparc_spmm")
+        check(lib.sparc_spmm(n, nnz, P(rowptr), P(colidx), P(val), width, P(X), None, P(Z), None, 0, 0, 0, stream), "sparc_spmm")
 
     launch()
     torch.cuda.synchronize()
