@@ -40,6 +40,7 @@ typedef struct ihipStream_t* sparc_stream_t; /* == hipStream_t */
 #define SPARC_ERR_ARG (-1)     /* bad argument (NULL pointer, k out of range, ...) */
 #define SPARC_ERR_WS (-2)      /* workspace too small or misaligned */
 #define SPARC_ERR_LAUNCH (-3)  /* the HIP runtime refused a launch */
+#define SPARC_ERR_SIZE (-4)    /* the problem is larger than a fixed-size entry point supports */
 
 #define SPARC_MAX_K 64
 /* per-row constants used by the per-step kernels, float[m][8] */
@@ -157,6 +158,17 @@ int sparc_profile_end(double* total_ms, int64_t* launches);
 size_t sparc_gram_workspace_bytes(int64_t m, int k);
 int sparc_gram(int64_t m, int k, const float* A, int64_t lda, const float* B, int64_t ldb,
                double* G, void* ws, size_t ws_bytes, sparc_stream_t stream);
+/* sparc_gram without a workspace argument and without any allocation.  No counterpart in the
+ * reference: it is for callers that cannot allocate device memory or carry a workspace (code
+ * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  Same kernels,
+ * same fixed summation order and bitwise the same G as sparc_gram; the partial Gram matrices go
+ * to a 4 MiB array that is part of the library image on every GPU (128 blocks x 64 x 64 doubles),
+ * which covers every m and every k <= SPARC_MAX_K; anything beyond returns SPARC_ERR_SIZE.  The
+ * first call on a device looks the array's address up (with that device current); no call
+ * allocates.  All calls on one GPU share the array: calls that overlap on one GPU (different
+ * streams or threads) race. */
+int sparc_gram_static(int64_t m, int k, const float* A, int64_t lda, const float* B, int64_t ldb,
+                      double* G, sparc_stream_t stream);
 int sparc_orth_weights(int64_t m, int k, const double* G, const float* Yt, int64_t ld,
                        const int32_t* top_idx, int mode, float* Wo,
                        double* Rc, double* Rinv, double* signs, int32_t* info,

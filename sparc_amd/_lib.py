@@ -11,7 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsparc_hip.so")
 
 ERRORS = {-1: "SPARC_ERR_ARG (bad argument)", -2: "SPARC_ERR_WS (workspace too small or misaligned)",
-          -3: "SPARC_ERR_LAUNCH (HIP launch failed)"}
+          -3: "SPARC_ERR_LAUNCH (HIP launch failed)",
+          -4: "SPARC_ERR_SIZE (problem larger than the fixed-size entry point supports)"}
 
 
 class SparcHipError(RuntimeError):
@@ -42,6 +43,7 @@ _SIGS = {
     "sparc_profile_end": (c_int, [P, P]),
     "sparc_gram_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "sparc_gram": (c_int, [c_int64, c_int, P, c_int64, P, c_int64, P, P, c_size_t, P]),
+    "sparc_gram_static": (c_int, [c_int64, c_int, P, c_int64, P, c_int64, P, P]),
     "sparc_orth_weights": (c_int, [c_int64, c_int, P, P, c_int64, P, c_int, P, P, P, P, P, P]),
     "sparc_orth_apply": (c_int, [c_int64, c_int, P, c_int64, P, c_int, P, c_int64, P]),
     "sparc_orth_weights_bwd": (c_int, [c_int64, c_int, P, P, P, P, c_int, P, P]),

@@ -1,6 +1,8 @@
 // Orthonormalisation layer: Gram matrix on the f64 matrix cores, k x k Cholesky,
 // triangular inverse and Householder sign recovery in LDS, the product with the
 // orthonormalisation weights, and the backward of the whole chain.
+#include <mutex>
+
 #include "common.h"
 
 namespace {
@@ -470,15 +472,58 @@ extern "C" size_t sparc_gram_workspace_bytes(int64_t m, int k) {
     return sparc_align_up(static_cast<size_t>(gram_blocks(m)) * k * k * sizeof(double));
 }
 
+namespace {
+int gram_launch(int64_t m, int k, const float* A, int64_t lda, const float* B, int64_t ldb, double* G, double* slab,
+                hipStream_t stream);
+
+// Scratch of sparc_gram_static: the partial Gram matrices of at most GRAM_MAX_BLOCKS blocks.  Every GPU the
+// library runs on holds its own copy of this array at its own address for the life of the process; in host
+// code the name is only a handle for hipGetSymbolAddress, never a device pointer.
+constexpr size_t GRAM_STATIC_BYTES = static_cast<size_t>(GRAM_MAX_BLOCKS) * SPARC_MAX_K * SPARC_MAX_K * sizeof(double);
+static __device__ __align__(256) unsigned char scratch[GRAM_STATIC_BYTES];
+
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;
+void* g_scratch_ptr[MAX_DEVICES] = {};  // device address of `scratch` on each device, looked up once
+
+// The address of `scratch` on the current device (nullptr on failure).  The first call on a device asks
+// the runtime for it; later calls only read the table.
+void* scratch_on_current_device() {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return nullptr;
+        g_scratch_ptr[dev] = p;
+    }
+    return g_scratch_ptr[dev];
+}
+}  // namespace
+
 extern "C" int sparc_gram(int64_t m, int k, const float* A, int64_t lda, const float* B, int64_t ldb, double* G,
                           void* ws, size_t ws_bytes, sparc_stream_t stream) {
     if (m <= 0 || k < 1 || k > SPARC_MAX_K || !A || !B || !G || lda < k || ldb < k) return SPARC_ERR_ARG;
     if (!ws || ws_bytes < sparc_gram_workspace_bytes(m, k) || (reinterpret_cast<uintptr_t>(ws) & 255)) return SPARC_ERR_WS;
+    return gram_launch(m, k, A, lda, B, ldb, G, static_cast<double*>(ws), stream);
+}
+
+extern "C" int sparc_gram_static(int64_t m, int k, const float* A, int64_t lda, const float* B, int64_t ldb, double* G,
+                                 sparc_stream_t stream) {
+    if (m <= 0 || !A || !B || !G || lda < k || ldb < k) return SPARC_ERR_ARG;
+    if (k < 1 || k > SPARC_MAX_K || sparc_gram_workspace_bytes(m, k) > GRAM_STATIC_BYTES) return SPARC_ERR_SIZE;
+    void* slab = scratch_on_current_device();
+    if (!slab) return SPARC_ERR_LAUNCH;
+    return gram_launch(m, k, A, lda, B, ldb, G, static_cast<double*>(slab), stream);
+}
+
+namespace {
+int gram_launch(int64_t m, int k, const float* A, int64_t lda, const float* B, int64_t ldb, double* G, double* slab,
+                hipStream_t stream) {
     const int nb = gram_blocks(m);
     int64_t rpb = (m + nb - 1) / nb;
     rpb = (rpb + 15) / 16 * 16;
     const int nparts = static_cast<int>((m + rpb - 1) / rpb);
-    double* slab = static_cast<double*>(ws);
     const int nt = (k + 15) / 16;
     const dim3 g(static_cast<unsigned>(nparts)), b(256);
     switch (nt) {
@@ -492,6 +537,7 @@ extern "C" int sparc_gram(int64_t m, int k, const float* A, int64_t lda, const f
     SPARC_CHECK_LAUNCH();
     return SPARC_OK;
 }
+}  // namespace
 
 extern "C" int sparc_orth_weights(int64_t m, int k, const double* G, const float* Yt, int64_t ld,
                                   const int32_t* top_idx, int mode, float* Wo, double* Rc, double* Rinv,
