@@ -87,45 +87,49 @@ int sparc_affinity_prep(int64_t m, int64_t nnz, const int64_t* rowptr, const int
  * loss and the gradient in its epilogue.  Y is [m][ldy] with k <= ldy; gradY is [m][ldy].
  * loss is one device double. */
 size_t sparc_lap_workspace_bytes(int64_t m, int k, int ntiles);
+
+/* Cluster tiling (optional; NULL selects the plain row kernel).  A HOST struct that describes one
+ * device buffer of int32 in two parts:
+ *   ndesc descriptors  {q_begin, q_end, win_begin, win_end, slab, n_long, 0, 0}
+ *   m row records      {row, p0, n_in, n_before << 16 | n_after}
+ * The dense operand of a tiled pass is kept slab-major: slab s is a row-major [m][16 vec] matrix
+ * holding columns [s hw, (s+1) hw) of the A half and, in the training pass, the same columns of
+ * the A^T half behind them (hw = 8 vec columns per half; forward-only pass: hw = 16 vec columns).
+ * A workgroup stages rows [win_begin, win_end) of slab `slab` in LDS and produces the rows of records
+ * [q_begin, q_end), all inside its window.  A row's stored entries are [p0, p0 + n_before) with
+ * columns before the window, then n_in entries inside it (gathered from LDS), then n_after behind it
+ * (both outside runs are gathered from global memory; each at most 65535 long).  Records of one
+ * workgroup are sorted by n_in, longest first: the first n_long of them (rows with more than
+ * SPARC_TILE_LONG_ROW in-window entries) get a whole wavefront each, the others share a wavefront
+ * four at a time and the first of the four bounds its trip count: it MUST be the longest of the
+ * four.  Every (row, slab) pair must be produced exactly once; a descriptor with q_begin == q_end is
+ * an empty workgroup (padding that lets a caller place the workgroups of one window on one XCD:
+ * workgroup b runs on XCD b % 8).  kp (a multiple of hw, >= k) is the padded number of columns per
+ * half; rows = the largest window, rows * 64 * vec <= 128 KiB; nnz < 2^31. */
+typedef struct sparc_tiling {
+    const int32_t* buf; /* device */
+    int32_t ndesc;
+    int32_t rows;
+    int32_t vec;     /* floats per lane, 2 or 4 */
+    int32_t threads; /* workgroup size: a multiple of 64, at most 1024 */
+    int32_t kp;
+    int32_t dual;    /* 1: planned for the training pass (loss + gradient), 0: forward only */
+} sparc_tiling_t;
+#define SPARC_TILE_LONG_ROW 64
+
 int sparc_lap_fwd(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* colidx,
                   const float* val, const float* valT, const float* rowc, const double* coupling,
                   int k, int64_t ldy, const float* Y, double* loss, float* gradY,
-                  const int32_t* tiles, int ntiles, int tile_rows,
+                  const sparc_tiling_t* tiling,
                   void* ws, size_t ws_bytes, sparc_stream_t stream);
 
-/* Cluster tiling (optional, tiles == NULL selects the plain row kernel).  `tiles` is one device
- * buffer of int32 in two parts:
- *   ntiles descriptors  {q_begin, q_end, win_begin, win_end, slab, n_long, 0, 0}
- *   m row records       {row, lo, hi, n_out, col0, col1, val0, valT0, val1, valT1, 0, 0}
- * A workgroup with slab >= 0 stages rows [win_begin, win_end) of the dense operand (one column
- * slab wide) in LDS and produces the rows of records [q_begin, q_end), all inside its window.
- * [lo, hi) are the positions in colidx of the row's entries whose column lies in the window;
- * the row's other entries (n_out of them, at most SPARC_TILE_MAX_OUTSIDE) are repeated in the
- * record itself: column and the float bits of val / valT; they are gathered from global memory.
- * Records of one workgroup are sorted by hi - lo, longest first: the first n_long of them (rows
- * with more than SPARC_TILE_LONG_ROW in-window entries) get a whole wavefront each, the others
- * share a wavefront four at a time and the first of the four bounds its trip count: it MUST be
- * the longest of the four.  Rows
- * with more outside entries belong to workgroups with slab = -1, which gather the rows of their
- * records whole from global memory.  Every (row, slab) pair must be produced exactly once; a descriptor with q_begin == q_end is an empty
- * workgroup (padding that lets a caller place the workgroups of one window on one XCD: workgroup b runs
- * on XCD b % 8).  A
- * slab is 32 columns of each half for the training pass (slab < kp/32, kp = k rounded up to
- * 16/32/64; used when kp >= 32) or all 64 columns for the forward-only pass (slab = 0; used when
- * kp == 64).  tile_rows = the largest window, at most SPARC_TILE_MAX_ROWS; nnz < 2^31. */
-#define SPARC_TILE_MAX_ROWS 512
-#define SPARC_TILE_MAX_OUTSIDE 2
-#define SPARC_TILE_LONG_ROW 64
-
 /* Plain product Z = A X (+ X0 if X0 != NULL) on the same kernels, X, X0, Z [m][width] with
- * width in {16, 32, 64, 128} (tiles: width 64 only, slab 0).  Passing the mirrored values as
- * `val` gives A^T X; with tiles, val_is_mirrored != 0 then makes the kernel take the mirrored
- * value of the entries repeated in the row records as well.  Exposed for roofline
- * measurements on whole graphs. */
+ * width in {16, 32, 64, 128}; pass the mirrored values as `val` for A^T X.  With a tiling
+ * (dual = 0, kp = width = 16 vec: one slab, which is the row-major operand itself) the windowed
+ * kernel runs.  Exposed for roofline measurements on whole graphs. */
 int sparc_spmm(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* colidx,
                const float* val, int width, const float* X, const float* X0, float* Z,
-               const int32_t* tiles, int ntiles, int tile_rows, int val_is_mirrored,
-               sparc_stream_t stream);
+               const sparc_tiling_t* tiling, sparc_stream_t stream);
 
 /* Measurement aid (no counterpart in the reference): between begin and end, every launch of the
  * row-gather kernel with the given epilogue (1 = the two inner passes of sparc_lap_fwd and

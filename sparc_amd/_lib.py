@@ -19,6 +19,12 @@ class SparcHipError(RuntimeError):
     pass
 
 
+class Tiling(ctypes.Structure):
+    """sparc_tiling_t of include/sparc_hip.h: a host struct describing a device tiling buffer."""
+    _fields_ = [("buf", c_void_p), ("ndesc", c_int32), ("rows", c_int32), ("vec", c_int32), ("threads", c_int32),
+                ("kp", c_int32), ("dual", c_int32)]
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise SparcHipError(
@@ -37,8 +43,8 @@ _SIGS = {
     "sparc_affinity_prep_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "sparc_affinity_prep": (c_int, [c_int64, c_int64, P, P, P, P, c_double, P, P, P, P, c_size_t, P]),
     "sparc_lap_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
-    "sparc_lap_fwd": (c_int, [c_int64, c_int64, P, P, P, P, P, P, c_int, c_int64, P, P, P, P, c_int, c_int, P, c_size_t, P]),
-    "sparc_spmm": (c_int, [c_int64, c_int64, P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, P]),
+    "sparc_lap_fwd": (c_int, [c_int64, c_int64, P, P, P, P, P, P, c_int, c_int64, P, P, P, P, P, c_size_t, P]),
+    "sparc_spmm": (c_int, [c_int64, c_int64, P, P, P, c_int, P, P, P, P, P]),
     "sparc_profile_begin": (c_int, [c_int, c_int]),
     "sparc_profile_end": (c_int, [P, P]),
     "sparc_gram_workspace_bytes": (c_size_t, [c_int64, c_int]),

@@ -29,16 +29,15 @@ struct SpmmArgs {
     int64_t ldy;
     int k;
     float inv_m;
-    // LDS-tiled kernel: work descriptors int32[ndesc][8] = {q_begin, q_end, win_begin, win_end, slab, 0, 0, 0}
-    // over the row records rowinfo int32[m][12] (layout: include/sparc_hip.h)
+    // windowed kernel: work descriptors int32[ndesc][8] and row records int32[m][4] (layout: include/sparc_hip.h)
     const int32_t* desc;
     const int32_t* rowinfo;
-    bool rec_mirrored;  // single-width tiled pass: `val` holds the mirrored values, so take valT of the records' outside entries
-    int dbg;  // ablation switches for kernel timing experiments (0 in production)
     int ndesc;
-    int tile_rows;  // largest window (rows) over all descriptors
-    int kp;         // columns per half (dual) or per row (single) of the global operand
-    int wtot;       // floats per row of the global operand
+    int tile_rows;   // largest window (rows) over all descriptors
+    int vec;         // floats per lane: a slab row is 16 * vec floats
+    int threads;     // workgroup size
+    int64_t plane;   // floats between two slabs of the slab-major operand (m * 16 * vec)
+    int kp;          // columns per half (dual) or per row (single): the stride of M12
     // affinity preparation epilogue
     double* racc;  // [m][8] {sum sq, S 1, S c, S c2 (all off-diagonal), S_ii}
     const double* cvec;
@@ -46,8 +45,8 @@ struct SpmmArgs {
     int64_t col0;
 };
 
-// LDS budget of one tile: SPARC_TILE_MAX_ROWS rows x 256 bytes
-#define SPARC_TILE_LDS_BYTES (SPARC_TILE_MAX_ROWS * 256)
+// LDS budget of one window
+#define SPARC_TILE_LDS_BYTES (128 * 1024)
 
 int sparc_spmm_launch(int epi, int width, const SpmmArgs& a, hipStream_t stream);
 int64_t sparc_rows_blocks(int64_t m);

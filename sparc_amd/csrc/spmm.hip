@@ -17,7 +17,9 @@
 //
 // In "dual" mode X is [Yn | Yn/rho]: the left half is multiplied by A (val), the right half
 // by A^T (valT, same pattern), so W Yn and W^T Yn share one pass over the index stream.
+#include <cstdint>
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 
 #include "spmm.h"
@@ -25,45 +27,67 @@
 namespace {
 
 constexpr int ROWS_PER_BLOCK = 4;  // spmm_rows: one row per wave
-constexpr int TILED_THREADS = 1024;
-constexpr int TILED_WAVES = TILED_THREADS / 64;
+constexpr int WIN_MAX_THREADS = 1024;  // spmm_win: workgroup size is a launch parameter, up to 16 waves
 
 // ------------------------------------------------------------------ shared epilogue
-// A lane owns 4 consecutive columns of one row: `gcol` is their offset inside the row of the
-// global operand (row stride wtot floats), `cl` their index inside the half (0..kp-1), `right`
-// tells the A^T half from the A half, `half` is the lane distance between the two halves.
+// A lane owns VEC consecutive columns of one row: `cl` is their index inside the half (0..kp-1),
+// `right` tells the A^T half from the A half, `half` is the lane distance between the two halves.
+template <int VEC>
 struct RowPre {  // what the epilogue reads of its own row, requested before the gathers
-    float4 x0, rc0, rc1;
+    float x0[VEC];
+    float4 rc0, rc1;
 };
 
+template <int VEC>
 struct LapConst {  // per-lane constants of the Laplacian epilogue: rows of M1 / M2 and the 3x3 coupling
-    float4 ma, mb, mc;
+    float ma[VEC], mb[VEC], mc[VEC];
     float cf[9];
 };
 
-template <int EPI>
-__device__ __forceinline__ LapConst lap_const(const SpmmArgs& a, const int kp, const int cl, const bool right) {
-    LapConst c;
-    c.ma = c.mb = c.mc = make_float4(0.f, 0.f, 0.f, 0.f);
+template <int VEC>
+__device__ __forceinline__ void load_vec(float (&dst)[VEC], const float* __restrict__ src) {
+    typedef float V __attribute__((ext_vector_type(VEC)));
+    const V v = *reinterpret_cast<const V*>(src);
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) dst[q] = v[q];
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* __restrict__ dst, const float (&src)[VEC]) {
+    typedef float V __attribute__((ext_vector_type(VEC)));
+    V v;
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) v[q] = src[q];
+    *reinterpret_cast<V*>(dst) = v;
+}
+
+template <int VEC, int EPI>
+__device__ __forceinline__ LapConst<VEC> lap_const(const SpmmArgs& a, const int cl, const bool right) {
+    LapConst<VEC> c;
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) c.ma[q] = c.mb[q] = c.mc[q] = 0.f;
 #pragma unroll
     for (int i = 0; i < 9; ++i) c.cf[i] = 0.f;
     if (EPI == EPI_LAP_SINGLE || EPI == EPI_LAP_DUAL) {
+        const int kp = a.kp;
         const float* Mb = a.M12 + (right ? 3 * kp : 0) + cl;
-        c.ma = *reinterpret_cast<const float4*>(Mb);
-        c.mb = *reinterpret_cast<const float4*>(Mb + kp);
-        c.mc = *reinterpret_cast<const float4*>(Mb + 2 * kp);
+        load_vec<VEC>(c.ma, Mb);
+        load_vec<VEC>(c.mb, Mb + kp);
+        load_vec<VEC>(c.mc, Mb + 2 * kp);
 #pragma unroll
         for (int i = 0; i < 9; ++i) c.cf[i] = a.M12[6 * kp + i];
     }
     return c;
 }
 
-template <int EPI>
-__device__ __forceinline__ RowPre row_preload(const SpmmArgs& a, const int64_t row, const int wtot, const int gcol) {
-    RowPre r;
-    r.x0 = r.rc0 = r.rc1 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (EPI == EPI_ADD_X0 || EPI == EPI_LAP_SINGLE || EPI == EPI_LAP_DUAL)
-        r.x0 = *reinterpret_cast<const float4*>(a.X0 + row * wtot + gcol);
+// x0p: this lane's columns of the row's own operand (EPI_ADD_X0 and the Laplacian epilogues)
+template <int VEC, int EPI>
+__device__ __forceinline__ RowPre<VEC> row_preload(const SpmmArgs& a, const int64_t row, const float* __restrict__ x0p) {
+    RowPre<VEC> r;
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) r.x0[q] = 0.f;
+    r.rc0 = r.rc1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (EPI == EPI_ADD_X0 || EPI == EPI_LAP_SINGLE || EPI == EPI_LAP_DUAL) load_vec<VEC>(r.x0, x0p);
     if (EPI == EPI_LAP_SINGLE || EPI == EPI_LAP_DUAL) {
         r.rc0 = *reinterpret_cast<const float4*>(a.rowc + row * SPARC_ROWC);
         r.rc1 = *reinterpret_cast<const float4*>(a.rowc + row * SPARC_ROWC + 4);
@@ -71,47 +95,36 @@ __device__ __forceinline__ RowPre row_preload(const SpmmArgs& a, const int64_t r
     return r;
 }
 
-// ROWS = rows per wave: 1 (the wave's owner lanes hold one row) or 4 (one row per 16-lane group).
-template <int ROWS>
-__device__ __forceinline__ double rows_sum(double v) {
-    if (ROWS == 1) return wave_sum(v);
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-}
-
-template <bool DUAL, int EPI, int ROWS = 1>
+// outp: where this lane's VEC results of the row go (store epilogues); colbase: index of the lane's first
+// column in the identity / statistics epilogues of the affinity preparation.
+template <int VEC, bool DUAL, int EPI>
 __device__ __forceinline__ void row_epilogue(const SpmmArgs& a, const int64_t row, const int lane, const bool owner,
-                                             const int half, const int kp, const int wtot, const int gcol,
-                                             const int cl, const bool right, const RowPre& pre, const LapConst& lc,
-                                             float4 acc, double& wloss) {
-    const int64_t ro = row * wtot + gcol;
+                                             const int half, const int cl, const bool right, const RowPre<VEC>& pre,
+                                             const LapConst<VEC>& lc, float (&acc)[VEC], float* __restrict__ outp,
+                                             const int64_t colbase, double& wloss) {
     if (EPI == EPI_STORE) {
-        if (owner) *reinterpret_cast<float4*>(a.out + ro) = acc;
+        if (owner) store_vec<VEC>(outp, acc);
     } else if (EPI == EPI_ADD_X0) {
         if (owner) {
-            const float4 x0 = pre.x0;
-            *reinterpret_cast<float4*>(a.out + ro) = make_float4(acc.x + x0.x, acc.y + x0.y, acc.z + x0.z, acc.w + x0.w);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) acc[q] += pre.x0[q];
+            store_vec<VEC>(outp, acc);
         }
     } else if (EPI == EPI_ADD_IDENT) {
         if (owner) {
-            const int64_t cb = a.col0 + gcol;
-            acc.x += (cb + 0 == row) ? 1.f : 0.f;
-            acc.y += (cb + 1 == row) ? 1.f : 0.f;
-            acc.z += (cb + 2 == row) ? 1.f : 0.f;
-            acc.w += (cb + 3 == row) ? 1.f : 0.f;
-            *reinterpret_cast<float4*>(a.out + ro) = acc;
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) acc[q] += (colbase + q == row) ? 1.f : 0.f;
+            store_vec<VEC>(outp, acc);
         }
     } else if (EPI == EPI_PREP_ACC) {
-        // acc holds S[row, col0 + gcol .. +3]; gather the row statistics of S
+        // acc holds S[row, colbase .. colbase + VEC): gather the row statistics of S
         double ss = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0;
         if (owner) {
-            const float vals[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int64_t cj = a.col0 + gcol + q;
+            for (int q = 0; q < VEC; ++q) {
+                const int64_t cj = colbase + q;
                 if (cj < a.m && cj != row) {
-                    const double sv = static_cast<double>(vals[q]);
+                    const double sv = static_cast<double>(acc[q]);
                     ss += sv * sv;
                     s0 += sv;
                     s1 += sv * a.cvec[cj];
@@ -119,15 +132,15 @@ __device__ __forceinline__ void row_epilogue(const SpmmArgs& a, const int64_t ro
                 }
             }
         }
-        ss = rows_sum<ROWS>(ss); s0 = rows_sum<ROWS>(s0); s1 = rows_sum<ROWS>(s1); s2 = rows_sum<ROWS>(s2);
-        if (owner && (ROWS == 1 ? lane == 0 : (lane & 15) == 0)) {
+        ss = wave_sum(ss); s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+        if (owner && lane == 0) {
             double* r = a.racc + row * 8;
             r[0] += ss; r[1] += s0; r[2] += s1; r[3] += s2;
         }
     } else {  // EPI_LAP_SINGLE / EPI_LAP_DUAL
         // rowc: {+-1/rho, S_ii, d+cw, 1/sqrt(d)}, {r, r2, c, c2}; a negative 1/rho marks a row without
         // off-diagonal entries, whose chain result is exactly S_ii x and is dropped instead of cancelled
-        const float4 rc0 = pre.rc0, rc1 = pre.rc1, x0 = pre.x0;
+        const float4 rc0 = pre.rc0, rc1 = pre.rc1;
         const bool isolated = rc0.x < 0.f;
         const float irho = fabsf(rc0.x);
         const float* Cf = lc.cf;  // the 3x3 coupling, row-major
@@ -135,34 +148,23 @@ __device__ __forceinline__ void row_epilogue(const SpmmArgs& a, const int64_t ro
         const float ldiag = (Cf[0] + Cf[1] * rc1.z + Cf[2] * rc1.w) + rc1.x * (Cf[3] + Cf[4] * rc1.z + Cf[5] * rc1.w) +
                             rc1.y * (Cf[6] + Cf[7] * rc1.z + Cf[8] * rc1.w);
         const float u1 = right ? rc1.z : rc1.x, u2 = right ? rc1.w : rc1.y;
-        const float4 ma = lc.ma, mb = lc.mb, mc = lc.mc;
-        float4 t;
-        t.x = (isolated ? 0.f : acc.x - rc0.y * x0.x) + ((ma.x + u1 * mb.x + u2 * mc.x) - ldiag * x0.x);
-        t.y = (isolated ? 0.f : acc.y - rc0.y * x0.y) + ((ma.y + u1 * mb.y + u2 * mc.y) - ldiag * x0.y);
-        t.z = (isolated ? 0.f : acc.z - rc0.y * x0.z) + ((ma.z + u1 * mb.z + u2 * mc.z) - ldiag * x0.z);
-        t.w = (isolated ? 0.f : acc.w - rc0.y * x0.w) + ((ma.w + u1 * mb.w + u2 * mc.w) - ldiag * x0.w);
-        float4 wt = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (DUAL) {  // W^T Yn sits `half` lanes to the right of W Yn
-            wt.x = __shfl(t.x, lane + half);
-            wt.y = __shfl(t.y, lane + half);
-            wt.z = __shfl(t.z, lane + half);
-            wt.w = __shfl(t.w, lane + half);
+        float t[VEC], wt[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            t[q] = (isolated ? 0.f : acc[q] - rc0.y * pre.x0[q]) + ((lc.ma[q] + u1 * lc.mb[q] + u2 * lc.mc[q]) - ldiag * pre.x0[q]);
+            wt[q] = DUAL ? __shfl(t[q], lane + half) : 0.f;  // W^T Yn sits `half` lanes to the right of W Yn
         }
         double dot = 0.0;
         if (owner && !right) {
-            const float4 wy = make_float4(irho * t.x, irho * t.y, irho * t.z, irho * t.w);
             const float hd = 0.5f * rc0.z;
-            const float ly0 = hd * x0.x - wy.x, ly1 = hd * x0.y - wy.y, ly2 = hd * x0.z - wy.z, ly3 = hd * x0.w - wy.w;
-            dot = static_cast<double>(x0.x) * ly0 + static_cast<double>(x0.y) * ly1 +
-                  static_cast<double>(x0.z) * ly2 + static_cast<double>(x0.w) * ly3;
-            if (DUAL) {
-                const float sc = a.inv_m * rc0.w;
-                const float gy[4] = {(rc0.z * x0.x - wy.x - wt.x) * sc, (rc0.z * x0.y - wy.y - wt.y) * sc,
-                                     (rc0.z * x0.z - wy.z - wt.z) * sc, (rc0.z * x0.w - wy.w - wt.w) * sc};
-                float* gp = a.gradY + row * a.ldy + cl;
+            const float sc = a.inv_m * rc0.w;
+            float* gp = DUAL ? a.gradY + row * a.ldy + cl : nullptr;
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (cl + q < a.k) gp[q] = gy[q];
+            for (int q = 0; q < VEC; ++q) {
+                const float wy = irho * t[q];
+                const float ly = hd * pre.x0[q] - wy;
+                dot += static_cast<double>(pre.x0[q]) * ly;
+                if (DUAL && cl + q < a.k) gp[q] = (rc0.z * pre.x0[q] - wy - wt[q]) * sc;
             }
         }
         wloss += dot;  // per lane; summed over the wave once, by the caller
@@ -206,7 +208,7 @@ __device__ __forceinline__ void wave_row_global(const SpmmArgs& a, const int64_t
     constexpr int HALF = LR / 2;
     const int g = lane / LR, lr = lane % LR;
     const int64_t p0 = a.rowptr[row], p1 = a.rowptr[row + 1];
-    const RowPre pre = row_preload<EPI>(a, row, W, lr * 4);
+    const RowPre<4> pre = row_preload<4, EPI>(a, row, a.X0 ? a.X0 + row * W + lr * 4 : nullptr);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int64_t p = p0; p < p1; p += 64) {
         const int cnt = static_cast<int>(min(static_cast<int64_t>(64), p1 - p));
@@ -236,10 +238,11 @@ __device__ __forceinline__ void wave_row_global(const SpmmArgs& a, const int64_t
         acc.w += __shfl_xor(acc.w, off);
     }
     const bool right = DUAL && lr >= HALF;
-    const int kp = DUAL ? W / 2 : W;
     const int cl = (DUAL ? (lr % HALF) : lr) * 4;
-    const LapConst lc = lap_const<EPI>(a, kp, cl, right);
-    row_epilogue<DUAL, EPI>(a, row, lane, g == 0, HALF, kp, W, lr * 4, cl, right, pre, lc, acc, wloss);
+    const LapConst<4> lc = lap_const<4, EPI>(a, cl, right);
+    float accv[4] = {acc.x, acc.y, acc.z, acc.w};
+    row_epilogue<4, DUAL, EPI>(a, row, lane, g == 0, HALF, cl, right, pre, lc, accv,
+                               a.out ? a.out + row * W + lr * 4 : nullptr, a.col0 + lr * 4, wloss);
 }
 
 template <int LR, bool DUAL, int EPI>
@@ -261,354 +264,334 @@ __global__ __launch_bounds__(256) void spmm_rows(const SpmmArgs a) {
     }
 }
 
-// ------------------------------------------------------------------ spmm_tiled
-// One workgroup = (window of rows, column slab, part of the window's rows).  A wave works on FOUR
-// rows at a time, one per 16-lane DPP row: lane (g, lr) owns 4 columns (16 bytes) of the slab of
-// row g.  The 16 lanes of a row load 16 consecutive stored entries; step u broadcasts entry u
-// inside each DPP row (v_mov_dpp row_newbcast) and gathers the operand row from the LDS window
-// with one ds_read_b128.  Rows arrive sorted by length (rowinfo), so the four rows of a wave are
-// equally long and row 0 of the wave bounds the trip count.  Rows with entries outside their
-// window (rare in a cluster batch) are not tiled at all: workgroups whose descriptor carries
-// slab < 0 gather them whole from global memory, so the hot loop has no second path.
-template <int N>
-__device__ __forceinline__ int row_bcast(const int x) {  // lane N of every 16-lane DPP row, to the whole row
-    return __builtin_amdgcn_mov_dpp(x, 0x150 + N, 0xf, 0xf, false);
-}
-template <int N>
-__device__ __forceinline__ float row_bcastf(const float x) {
-    return __int_as_float(row_bcast<N>(__float_as_int(x)));
-}
+// ------------------------------------------------------------------ spmm_win
+// One workgroup = (window of rows, column slab, part of the window's rows).  The dense operand is kept
+// slab-major for this kernel: slab s is a row-major [m][16 VEC] matrix (dual: 8 VEC columns of the A
+// half, then the same 8 VEC columns of the A^T half), so a window's rows of one slab are one contiguous
+// piece of memory, staged in LDS by asynchronous global->LDS copies.  A wave works on FOUR rows at a
+// time, one per 16-lane DPP row: lane (g, lr) owns VEC columns of the slab of row g.  The 16 lanes of a
+// DPP row hold 16 consecutive stored entries; step u broadcasts entry u inside each DPP row
+// (row_newbcast) and gathers the operand row with one ds_read (entries whose column lies in the window,
+// i.e. nearly all of a cluster batch) or one global load (the others).  Rows arrive sorted by length, so
+// the four rows of a wave are about equally long and the first bounds the trip count.
+template <int VEC> struct VecOf;
+template <> struct VecOf<2> { typedef float T __attribute__((ext_vector_type(2))); };
+template <> struct VecOf<4> { typedef float T __attribute__((ext_vector_type(4))); };
 
 struct Chunk {  // 16 stored entries of one row, one per lane of the DPP row
-    int addr;   // byte offset of the operand row inside the LDS window
+    int addr;   // in-window: byte offset of the operand row inside the LDS window; outside: the operand row
     float v, vt;
 };
 
+// Entry at position p of the index stream (idle lanes: operand row 0 with a zero weight).
 template <bool DUAL>
-__device__ __forceinline__ Chunk load_chunk(const SpmmArgs& a, const int lo, const int hi, const int base, const int lr,
-                                            const int w0, const int own_addr) {
+__device__ __forceinline__ Chunk load_entry(const SpmmArgs& a, const int p, const bool live) {
     Chunk ck;
-    ck.addr = own_addr;  // idle lanes: a row of the window, zero weight
+    ck.addr = 0;
     ck.v = 0.f;
     ck.vt = 0.f;
-    const int p = lo + base + lr;  // lr: position of the lane's entry inside the chunk
-    if (p < hi) {
-        ck.addr = (a.col[p] - w0) << 8;
+    if (live) {
+        ck.addr = a.col[p];
         ck.v = a.val[p];
         if (DUAL) ck.vt = a.valT[p];
     }
     return ck;
 }
 
-// One entry of each of the wave's four rows.  The broadcasts are folded into the instructions that use
-// them: the LDS address is one v_add_u32 with a DPP source (lane U of the row + this lane's column
-// offset), and in the training pass the weight is two DPP moves into one register, val into the lanes
-// of the A half (DPP banks 0-1) and valT into the lanes of the A^T half (banks 2-3): no select.
-typedef float lds_vec4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) const lds_vec4 lds_float4;
-
+// The broadcasts are compiler-visible DPP operations (the wait states between a vector write and a DPP
+// read of the same register are inserted by the compiler) and fold into the instructions that use them:
+// the address is one v_add_u32 with a DPP source, and in the training pass the weight is two DPP moves
+// into one register, val into the lanes of the A half (DPP banks 0-1) and valT into the lanes of the
+// A^T half (banks 2-3): no select.
 template <int U>
-__device__ __forceinline__ int step_addr(const Chunk& ck, const int lane_base) {
-    // lane U's row offset + this lane's column offset + the window's LDS base: an absolute LDS address.
-    // Compiler-visible DPP (folded into one v_add_u32_dpp), so that the VALU-write -> DPP-read wait states
-    // are inserted by the hazard recognizer.
-    return __builtin_amdgcn_update_dpp(0, ck.addr, 0x150 + U, 0xf, 0xf, false) + lane_base;
+__device__ __forceinline__ int bcast_add(const int x, const int base) {  // lane U of the DPP row + this lane's base
+    return __builtin_amdgcn_update_dpp(0, x, 0x150 + U, 0xf, 0xf, false) + base;
 }
 
 template <bool DUAL, int U>
 __device__ __forceinline__ float step_weight(const Chunk& ck) {
-    if (DUAL) {  // val into DPP banks 0-1 (the A half), valT into banks 2-3 (the A^T half)
+    if (DUAL) {
         int w = __builtin_amdgcn_update_dpp(0, __float_as_int(ck.v), 0x150 + U, 0xf, 0x3, false);
         w = __builtin_amdgcn_update_dpp(w, __float_as_int(ck.vt), 0x150 + U, 0xf, 0xc, false);
         return __int_as_float(w);
     }
-    return row_bcastf<U>(ck.v);
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ck.v), 0x150 + U, 0xf, 0xf, false));
 }
 
-__device__ __forceinline__ void step_fma(float4& acc, const float w, const lds_vec4 x) {
-    acc.x = fmaf(w, x[0], acc.x);
-    acc.y = fmaf(w, x[1], acc.y);
-    acc.z = fmaf(w, x[2], acc.z);
-    acc.w = fmaf(w, x[3], acc.w);
+template <int VEC>
+__device__ __forceinline__ void vec_fma(float (&acc)[VEC], const float w, const typename VecOf<VEC>::T x) {
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) acc[q] = fmaf(w, x[q], acc[q]);
 }
 
-// Four entries of each of the wave's four rows.  The broadcasts are folded into the instructions that
-// use them: the LDS address is one v_add_u32 with a DPP source, and in the training pass the weight is
-// two DPP moves into one register, val into the lanes of the A half (DPP banks 0-1) and valT into the
-// lanes of the A^T half (banks 2-3): no select.  The four LDS reads are requested together and the
-// products alternate between two accumulators.
-template <bool DUAL, int U>
-__device__ __forceinline__ void tile_step4(float4& acc0, float4& acc1, const Chunk& ck, const int lane_base) {
-    const int a0 = step_addr<U>(ck, lane_base), a1 = step_addr<U + 1>(ck, lane_base);
-    const int a2 = step_addr<U + 2>(ck, lane_base), a3 = step_addr<U + 3>(ck, lane_base);
-    const lds_vec4 x0 = *(lds_float4*)(unsigned long)(unsigned)a0;
-    const lds_vec4 x1 = *(lds_float4*)(unsigned long)(unsigned)a1;
-    const lds_vec4 x2 = *(lds_float4*)(unsigned long)(unsigned)a2;
-    const lds_vec4 x3 = *(lds_float4*)(unsigned long)(unsigned)a3;
+// Four in-window entries of each of the wave's four rows: the four LDS reads are requested together and
+// the products alternate between two accumulators.  lane_base = this lane's column offset inside a
+// window row + the window's LDS base address.
+template <int VEC, bool DUAL, int U>
+__device__ __forceinline__ void lds_step4(float (&acc0)[VEC], float (&acc1)[VEC], const Chunk& ck, const int lane_base) {
+    typedef typename VecOf<VEC>::T V;
+    typedef __attribute__((address_space(3))) const V LdsV;
+    const int a0 = bcast_add<U>(ck.addr, lane_base), a1 = bcast_add<U + 1>(ck.addr, lane_base);
+    const int a2 = bcast_add<U + 2>(ck.addr, lane_base), a3 = bcast_add<U + 3>(ck.addr, lane_base);
+    const V x0 = *(LdsV*)(unsigned long)(unsigned)a0;
+    const V x1 = *(LdsV*)(unsigned long)(unsigned)a1;
+    const V x2 = *(LdsV*)(unsigned long)(unsigned)a2;
+    const V x3 = *(LdsV*)(unsigned long)(unsigned)a3;
     const float w0 = step_weight<DUAL, U>(ck), w1 = step_weight<DUAL, U + 1>(ck);
     const float w2 = step_weight<DUAL, U + 2>(ck), w3 = step_weight<DUAL, U + 3>(ck);
-    step_fma(acc0, w0, x0);
-    step_fma(acc1, w1, x1);
-    step_fma(acc0, w2, x2);
-    step_fma(acc1, w3, x3);
+    vec_fma<VEC>(acc0, w0, x0);
+    vec_fma<VEC>(acc1, w1, x1);
+    vec_fma<VEC>(acc0, w2, x2);
+    vec_fma<VEC>(acc1, w3, x3);
 }
 
-// The same with two reads in flight and one accumulator: for the epilogues that leave few registers.
-template <bool DUAL, int U>
-__device__ __forceinline__ void tile_step2x2(float4& acc, const Chunk& ck, const int lane_base) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int a0 = h ? step_addr<U + 2>(ck, lane_base) : step_addr<U>(ck, lane_base);
-        const int a1 = h ? step_addr<U + 3>(ck, lane_base) : step_addr<U + 1>(ck, lane_base);
-        const lds_vec4 x0 = *(lds_float4*)(unsigned long)(unsigned)a0;
-        const lds_vec4 x1 = *(lds_float4*)(unsigned long)(unsigned)a1;
-        const float w0 = h ? step_weight<DUAL, U + 2>(ck) : step_weight<DUAL, U>(ck);
-        const float w1 = h ? step_weight<DUAL, U + 3>(ck) : step_weight<DUAL, U + 1>(ck);
-        step_fma(acc, w0, x0);
-        step_fma(acc, w1, x1);
-    }
+// `steps` (1..16, wave-uniform) entries of an in-window chunk, four at a time (idle steps carry a zero weight)
+template <int VEC, bool DUAL>
+__device__ __forceinline__ void lds_chunk(float (&acc0)[VEC], float (&acc1)[VEC], const Chunk& ck, const int steps,
+                                          const int lane_base) {
+    if (steps > 0) lds_step4<VEC, DUAL, 0>(acc0, acc1, ck, lane_base);
+    if (steps > 4) lds_step4<VEC, DUAL, 4>(acc0, acc1, ck, lane_base);
+    if (steps > 8) lds_step4<VEC, DUAL, 8>(acc0, acc1, ck, lane_base);
+    if (steps > 12) lds_step4<VEC, DUAL, 12>(acc0, acc1, ck, lane_base);
 }
 
-// `steps` (1..16, wave-uniform, in an SGPR) entries of the chunk, four at a time (idle steps carry a
-// zero weight); lane_base = this lane's column offset inside a window row + the window's LDS base
-template <bool DUAL, bool WIDE>
-__device__ __forceinline__ void tile_chunk(float4& acc, const Chunk& ck, const int steps, const int lane_base) {
-    if (WIDE) {
-        float4 acc1 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (steps > 0) tile_step4<DUAL, 0>(acc, acc1, ck, lane_base);
-        if (steps > 4) tile_step4<DUAL, 4>(acc, acc1, ck, lane_base);
-        if (steps > 8) tile_step4<DUAL, 8>(acc, acc1, ck, lane_base);
-        if (steps > 12) tile_step4<DUAL, 12>(acc, acc1, ck, lane_base);
-        acc.x += acc1.x;
-        acc.y += acc1.y;
-        acc.z += acc1.z;
-        acc.w += acc1.w;
-    } else {
-        if (steps > 0) tile_step2x2<DUAL, 0>(acc, ck, lane_base);
-        if (steps > 4) tile_step2x2<DUAL, 4>(acc, ck, lane_base);
-        if (steps > 8) tile_step2x2<DUAL, 8>(acc, ck, lane_base);
-        if (steps > 12) tile_step2x2<DUAL, 12>(acc, ck, lane_base);
-    }
+// Entries outside the window: the operand rows come from global memory (the slab's rows are 16 VEC floats
+// apart).  Issue and use are separate so that the loads of a slot's first four outside entries travel
+// behind its LDS work.
+template <int VEC>
+struct Outside4 {
+    typename VecOf<VEC>::T x[4];
+};
+
+template <int VEC, int U>
+__device__ __forceinline__ Outside4<VEC> outside_issue4(const Chunk& ck, const float* __restrict__ lane_ptr) {
+    typedef typename VecOf<VEC>::T V;
+    Outside4<VEC> o;
+    const int r0 = bcast_add<U>(ck.addr, 0), r1 = bcast_add<U + 1>(ck.addr, 0);
+    const int r2 = bcast_add<U + 2>(ck.addr, 0), r3 = bcast_add<U + 3>(ck.addr, 0);
+    o.x[0] = *reinterpret_cast<const V*>(lane_ptr + static_cast<int64_t>(r0) * (16 * VEC));
+    o.x[1] = *reinterpret_cast<const V*>(lane_ptr + static_cast<int64_t>(r1) * (16 * VEC));
+    o.x[2] = *reinterpret_cast<const V*>(lane_ptr + static_cast<int64_t>(r2) * (16 * VEC));
+    o.x[3] = *reinterpret_cast<const V*>(lane_ptr + static_cast<int64_t>(r3) * (16 * VEC));
+    return o;
 }
 
-template <bool DUAL, int EPI>
-__global__ __launch_bounds__(TILED_THREADS) void spmm_tiled(const SpmmArgs a) {
-    extern __shared__ float4 tile[];  // [window rows][16 lanes] float4
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+template <int VEC, bool DUAL, int U>
+__device__ __forceinline__ void outside_use4(float (&acc0)[VEC], float (&acc1)[VEC], const Chunk& ck, const Outside4<VEC>& o) {
+    vec_fma<VEC>(acc0, step_weight<DUAL, U>(ck), o.x[0]);
+    vec_fma<VEC>(acc1, step_weight<DUAL, U + 1>(ck), o.x[1]);
+    vec_fma<VEC>(acc0, step_weight<DUAL, U + 2>(ck), o.x[2]);
+    vec_fma<VEC>(acc1, step_weight<DUAL, U + 3>(ck), o.x[3]);
+}
+
+template <int VEC, bool DUAL, int U>
+__device__ __forceinline__ void outside_step4(float (&acc0)[VEC], float (&acc1)[VEC], const Chunk& ck,
+                                              const float* __restrict__ lane_ptr) {
+    const Outside4<VEC> o = outside_issue4<VEC, U>(ck, lane_ptr);
+    outside_use4<VEC, DUAL, U>(acc0, acc1, ck, o);
+}
+
+// steps [first, steps) of an outside chunk, four at a time
+template <int VEC, bool DUAL>
+__device__ __forceinline__ void outside_chunk(float (&acc0)[VEC], float (&acc1)[VEC], const Chunk& ck, const int first,
+                                              const int steps, const float* __restrict__ lane_ptr) {
+    if (first <= 0 && steps > 0) outside_step4<VEC, DUAL, 0>(acc0, acc1, ck, lane_ptr);
+    if (first <= 4 && steps > 4) outside_step4<VEC, DUAL, 4>(acc0, acc1, ck, lane_ptr);
+    if (first <= 8 && steps > 8) outside_step4<VEC, DUAL, 8>(acc0, acc1, ck, lane_ptr);
+    if (steps > 12) outside_step4<VEC, DUAL, 12>(acc0, acc1, ck, lane_ptr);
+}
+
+template <int VEC, bool DUAL, int EPI>
+__global__ __launch_bounds__(WIN_MAX_THREADS) void spmm_win(const SpmmArgs a) {
+    extern __shared__ float4 tile[];  // [window rows][16 lanes][VEC floats]
+    typedef typename VecOf<VEC>::T V;
+    constexpr int RW = 16 * VEC;      // floats per slab row
+    constexpr int ROWB = RW * 4;      // bytes per slab row
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int g = lane >> 4, lr = lane & 15;
     const int32_t* d = a.desc + static_cast<int64_t>(blockIdx.x) * 8;
-    const int q_begin = d[0], q_end = d[1], w0 = d[2], wn = d[3] - d[2], slab = d[4];
-    const int kp = a.kp, wtot = a.wtot;
-    if (slab < 0) {
-        // Rows with entries outside their window: this workgroup gathers them whole from global
-        // memory (records [q_begin, q_end) of the row list, one row per wave at a time).
-        double gl = 0.0;
-        const int g_end = (a.dbg & 8) ? q_begin : q_end;
-        for (int q = q_begin + wave; q < g_end; q += TILED_WAVES) {
-            const int64_t row = a.rowinfo[12 * static_cast<int64_t>(q)];
-            if (DUAL) {
-                if (kp == 64) wave_row_global<32, true, EPI>(a, row, lane, gl);
-                else wave_row_global<16, true, EPI>(a, row, lane, gl);
-            } else {
-                wave_row_global<16, false, EPI>(a, row, lane, gl);
-            }
-        }
-        if (EPI == EPI_LAP_SINGLE || EPI == EPI_LAP_DUAL) {
-            __shared__ double gw[TILED_WAVES];
-            gl = wave_sum(gl);
-            if (lane == 0) gw[wave] = gl;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                double t = 0.0;
-                for (int w = 0; w < TILED_WAVES; ++w) t += gw[w];
-                a.loss_part[blockIdx.x] = t;
-            }
-        }
+    const int q_begin = d[0], q_end = d[1], w0 = d[2], wn = d[3] - d[2], slab = d[4], n_long = d[5];
+    const int nq = q_end - q_begin;
+    if (nq <= 0) {  // padding descriptor
+        if ((EPI == EPI_LAP_SINGLE || EPI == EPI_LAP_DUAL) && threadIdx.x == 0) a.loss_part[blockIdx.x] = 0.0;
         return;
     }
-    // columns of this lane: dual = 8 lanes (32 floats) of the A half + 8 lanes of the A^T half,
-    // single = 16 lanes (64 floats)
+    // columns of this lane inside its half (dual: 8 lanes for the A half, 8 for the A^T half)
     const bool right = DUAL && lr >= 8;
-    const int cl = DUAL ? slab * 32 + (lr & 7) * 4 : slab * 64 + lr * 4;
-    const int gcol = (right ? kp : 0) + cl;
+    const int cl = DUAL ? slab * (8 * VEC) + (lr & 7) * VEC : slab * RW + lr * VEC;
+    const int64_t slab_off = static_cast<int64_t>(slab) * a.plane;
+    const float* __restrict__ Xs = a.Xg + slab_off + lr * VEC;    // this lane's columns of operand row 0
+    const float* __restrict__ X0s = a.X0 ? a.X0 + slab_off + lr * VEC : nullptr;
+    float* __restrict__ outs = a.out ? a.out + slab_off + lr * VEC : nullptr;
 
-    // The records of this wave's first two slots are requested from global memory before anything else, so
-    // that their entry chunks can be requested while the window is still being staged (every later slot
-    // reads its record from the LDS copy made below).
-    const int nq = q_end - q_begin;
-    const int n_long = d[5];
-    const int nslots = (a.dbg & 1) ? 0 : n_long + (nq - n_long + 3) / 4;
-    auto slot_of = [&](const int round) { return round * TILED_WAVES + ((round & 1) ? TILED_WAVES - 1 - wave : wave); };
-    auto record_index = [&](const int slot) { return slot < n_long ? slot : n_long + (slot - n_long) * 4 + g; };
-    int4 early_ri[2];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int slot = slot_of(e), qi = record_index(slot);
-        early_ri[e] = make_int4(-1, 0, 0, 0);
-        if (slot < nslots && qi < nq)
-            early_ri[e] = reinterpret_cast<const int4*>(a.rowinfo)[(static_cast<int64_t>(q_begin) + qi) * 3];
-    }
-
-    {   // stage the window with asynchronous global->LDS copies (no register round trip): one wave
-        // instruction moves 64 x 16 bytes to LDS base + lane * 16, the source address is per lane
-        const float* src = a.Xg + static_cast<int64_t>(w0) * wtot + gcol;
-        const int n16 = (a.dbg & 4) ? 0 : wn * 16;
-        for (int base = wave * 64; base < n16; base += TILED_THREADS) {
-            const int i = base + lane;
-            if (i < n16)
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(src + static_cast<int64_t>(i >> 4) * wtot),
-                    (__attribute__((address_space(3))) void*)(tile + base), 16, 0, 0);
-        }
-    }
-    // the row records of this workgroup, in LDS: 3 x int4 per row =
-    // {row, lo, hi, n_outside}, {col0, col1, val0, valT0}, {val1, valT1, 0, 0}
-    __shared__ int4 info[SPARC_TILE_MAX_ROWS * 3];
-    for (int i = threadIdx.x; i < nq * 3; i += TILED_THREADS)
-        info[i] = reinterpret_cast<const int4*>(a.rowinfo)[static_cast<int64_t>(q_begin) * 3 + i];
-    const char* tile_bytes = reinterpret_cast<const char*>(tile);
-    constexpr bool WIDE = EPI != EPI_LAP_SINGLE && EPI != EPI_LAP_DUAL;   // the loss epilogues leave fewer registers
-    // this lane's column offset inside a window row plus the window's LDS base address
-    const int lr16 = lr * 16 + (int)(unsigned long)(__attribute__((address_space(3))) const char*)tile_bytes;
-    const LapConst lc = lap_const<EPI>(a, kp, cl, right);
-    // A wave owns slots wave, wave + 16, ... (4 rows each), sorted by work (longest first) and dealt in
-    // serpentine order.  Slots: the first n_long records are long rows (more than SPARC_TILE_LONG_ROW
-    // in-window entries), each worked on by the whole wave (DPP row g takes entries g, g + 4, ...; the four
-    // partial sums are merged at the end); the other records are taken four at a time, one row per DPP row.
-    // Up to two entries of a row may lie outside the window; their columns and values travel in the row
-    // record and their operand rows come from global memory.
+    // A wave owns slots wave, wave + nwaves, ... sorted by work (longest first) and dealt in serpentine
+    // order.  The first n_long records are long rows, each worked on by the whole wave (DPP row g takes
+    // entries g, g + 4, ...; the four partial sums are merged at the end); the other records are taken four
+    // at a time, one row per DPP row.  Record = {row, p0, n_in, n_before << 16 | n_after}: the row's stored
+    // entries are [p0, p0 + n_before) before the window, then n_in inside it, then n_after behind it.
+    const int nslots = n_long + (nq - n_long + 3) / 4;
+    const int4* __restrict__ rec = reinterpret_cast<const int4*>(a.rowinfo) + q_begin;
+    auto slot_of = [&](const int round) { return round * nwaves + ((round & 1) ? nwaves - 1 - wave : wave); };
+    auto load_record = [&](const int slot) {
+        const int qi = slot < n_long ? slot : n_long + (slot - n_long) * 4 + g;
+        int4 ri = make_int4(-1, 0, 0, 0);
+        if (slot < nslots && qi < nq) ri = rec[qi];
+        return ri;
+    };
     struct Slot {
         int4 ri;
-        Chunk c0, c1;
-        RowPre pre;
-        float ow0, ow1;
-        float4 ox0, ox1;
+        Chunk c0, c1, o0;  // the first two in-window chunks and the first outside chunk
     };
-    // The entry chunks of a slot are requested two slots ahead: global-memory latency hides behind two
-    // slots of LDS work (for the first two slots: behind the staging of the window).
+    // The entry chunks of a slot are requested two slots ahead, its record three: global-memory latency
+    // hides behind LDS work (for the first slots: behind the staging of the window).
     auto with_chunks = [&](const int4 ri, const int slot) {
         Slot s;
         const bool lng = slot < n_long;
         s.ri = ri;
         const int off = lng ? lr * 4 + g : lr;  // entry of this lane inside a chunk
-        s.c0 = load_chunk<DUAL>(a, s.ri.y, s.ri.z, 0, off, w0, 0);
-        s.c1 = load_chunk<DUAL>(a, s.ri.y, s.ri.z, lng ? 64 : 16, off, w0, 0);
+        const int nb = ri.w >> 16, no = nb + (ri.w & 0xffff);
+        const int lo = ri.y + nb, hi = lo + ri.z;
+        s.c0 = load_entry<DUAL>(a, lo + off, off < ri.z);
+        s.c0.addr = (s.c0.addr - (off < ri.z ? w0 : 0)) * ROWB;
+        const int off1 = off + (lng ? 64 : 16);
+        s.c1 = load_entry<DUAL>(a, lo + off1, off1 < ri.z);
+        s.c1.addr = (s.c1.addr - (off1 < ri.z ? w0 : 0)) * ROWB;
+        s.o0 = load_entry<DUAL>(a, off < nb ? ri.y + off : hi + (off - nb), off < no);
         return s;
     };
-    Slot cur = with_chunks(early_ri[0], slot_of(0)), nxt = with_chunks(early_ri[1], slot_of(1));
-    __syncthreads();  // the window and the records have landed (the barrier waits for the LDS copies)
+    const int4 r0 = load_record(slot_of(0)), r1 = load_record(slot_of(1));
+    int4 ri2 = load_record(slot_of(2));
 
-    // The epilogue operands and the outside operands of a slot are requested at the start of the slot's own
-    // round and arrive behind its LDS gather (carrying them two slots ahead as well costs registers: spills
-    // in the loss epilogues, and it measured slower for every epilogue).
-    auto fetch_operands = [&](Slot& s, const int slot) {
-        const bool lng = slot < n_long;
-        const int qi = record_index(slot);
-        s.ow0 = s.ow1 = 0.f;
-        s.ox0 = s.ox1 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (s.ri.x >= 0 && s.ri.w > 0 && (!lng || g == 0)) {
-            const int4 o0 = info[qi * 3 + 1];
-            const bool mirrored = right || a.rec_mirrored;   // which of the record's two values this lane multiplies by
-            s.ow0 = __int_as_float(mirrored ? o0.w : o0.z);
-            s.ox0 = *reinterpret_cast<const float4*>(a.Xg + static_cast<int64_t>(o0.x) * wtot + gcol);
-            if (s.ri.w > 1) {
-                const int4 o1 = info[qi * 3 + 2];
-                s.ow1 = __int_as_float(mirrored ? o1.y : o1.x);
-                s.ox1 = *reinterpret_cast<const float4*>(a.Xg + static_cast<int64_t>(o0.y) * wtot + gcol);
-            }
+    {   // stage the window: one wave instruction moves 64 x 16 bytes to LDS base + lane * 16
+        const float* src = a.Xg + slab_off + static_cast<int64_t>(w0) * RW;
+        const int n16 = wn * (ROWB / 16);
+        for (int base = wave * 64; base < n16; base += blockDim.x) {
+            const int i = base + lane;
+            if (i < n16)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 4),
+                                                 (__attribute__((address_space(3))) void*)(tile + base), 16, 0, 0);
         }
-        s.pre = row_preload<EPI_STORE>(a, 0, 0, 0);
-        if (s.ri.x >= 0) s.pre = row_preload<EPI>(a, s.ri.x, wtot, gcol);
-    };
-    auto fetch = [&](const int slot) {
-        const int qi = record_index(slot);
-        int4 ri = make_int4(-1, 0, 0, 0);
-        if (slot < nslots && qi < nq) ri = info[qi * 3];
-        return with_chunks(ri, slot);
-    };
+    }
+    Slot cur = with_chunks(r0, slot_of(0)), nxt = with_chunks(r1, slot_of(1));
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's copies into LDS have landed
+    __syncthreads();                     // ... and so have everybody else's
 
+    const int lane_base = lr * (VEC * 4) + (int)(unsigned long)(__attribute__((address_space(3))) const char*)tile;
+    const LapConst<VEC> lc = lap_const<VEC, EPI>(a, cl, right);
     double wloss = 0.0;
-    for (int round = 0; round * TILED_WAVES < nslots; ++round) {  // wave-uniform
-        const Slot nn = fetch(slot_of(round + 2));
-        const bool lng = slot_of(round) < n_long;  // wave-uniform
+    for (int round = 0; round * nwaves < nslots; ++round) {  // wave-uniform
+        const int slot = slot_of(round);
+        const Slot nn = with_chunks(ri2, slot_of(round + 2));
+        ri2 = load_record(slot_of(round + 3));
+        const bool lng = slot < n_long;  // wave-uniform
         const int4 ri = cur.ri;
-        // rows are sorted by length: DPP row 0 holds the longest of the four
-        const int nmax = __builtin_amdgcn_readfirstlane(ri.z - ri.y);
-        const int steps = (a.dbg & 2) ? 0 : (lng ? (nmax + 3) >> 2 : nmax);
+        const bool valid = ri.x >= 0;
+        const int nb = ri.w >> 16, no = nb + (ri.w & 0xffff);
+        const int lo = ri.y + nb, hi = lo + ri.z;
+        // rows are sorted by in-window length: DPP row 0 holds the longest of the four
+        const int nmax = __builtin_amdgcn_readfirstlane(ri.z);
+        const int steps = lng ? (nmax + 3) >> 2 : nmax;
         const int cstride = lng ? 64 : 16;  // entries per chunk
         const int off = lng ? lr * 4 + g : lr;
-        fetch_operands(cur, slot_of(round));
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (steps > 0) tile_chunk<DUAL, WIDE>(acc, cur.c0, min(steps, 16), lr16);
-        if (steps > 16) tile_chunk<DUAL, WIDE>(acc, cur.c1, min(steps - 16, 16), lr16);
-        for (int c = 2; c * 16 < steps; ++c) {
-            const Chunk ck = load_chunk<DUAL>(a, ri.y, ri.z, c * cstride, off, w0, 0);
-            tile_chunk<DUAL, WIDE>(acc, ck, min(steps - c * 16, 16), lr16);
+        int no_max = max(max(__builtin_amdgcn_readlane(no, 0), __builtin_amdgcn_readlane(no, 16)),
+                         max(__builtin_amdgcn_readlane(no, 32), __builtin_amdgcn_readlane(no, 48)));
+        const int osteps = lng ? (no_max + 3) >> 2 : no_max;
+        // the epilogue's own-row operands and the first four outside operand rows travel behind the LDS work
+        const RowPre<VEC> pre = row_preload<VEC, EPI>(a, valid ? ri.x : 0, X0s ? X0s + static_cast<int64_t>(valid ? ri.x : 0) * RW : nullptr);
+        Outside4<VEC> o4;
+        if (osteps > 0) o4 = outside_issue4<VEC, 0>(cur.o0, Xs);
+        float acc[VEC], acc1[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc[q] = acc1[q] = 0.f;
+        if (steps > 0) lds_chunk<VEC, DUAL>(acc, acc1, cur.c0, min(steps, 16), lane_base);
+        if (steps > 16) {
+            Chunk ck = cur.c1;
+            for (int c = 1; c * 16 < steps; ++c) {  // the next chunk is requested before this one is worked on
+                const int offn = (c + 1) * cstride + off;
+                Chunk cn = load_entry<DUAL>(a, lo + offn, offn < ri.z);
+                cn.addr = (cn.addr - (offn < ri.z ? w0 : 0)) * ROWB;
+                lds_chunk<VEC, DUAL>(acc, acc1, ck, min(steps - c * 16, 16), lane_base);
+                ck = cn;
+            }
         }
-        // the (at most two) entries outside the window
-        acc.x += fmaf(cur.ow1, cur.ox1.x, cur.ow0 * cur.ox0.x);
-        acc.y += fmaf(cur.ow1, cur.ox1.y, cur.ow0 * cur.ox0.y);
-        acc.z += fmaf(cur.ow1, cur.ox1.z, cur.ow0 * cur.ox0.z);
-        acc.w += fmaf(cur.ow1, cur.ox1.w, cur.ow0 * cur.ox0.w);
+        if (osteps > 0) {
+            outside_use4<VEC, DUAL, 0>(acc, acc1, cur.o0, o4);
+            outside_chunk<VEC, DUAL>(acc, acc1, cur.o0, 4, min(osteps, 16), Xs);
+            for (int c = 1; c * 16 < osteps; ++c) {
+                const int t = c * cstride + off;
+                const Chunk ck = load_entry<DUAL>(a, t < nb ? ri.y + t : hi + (t - nb), t < no);
+                outside_chunk<VEC, DUAL>(acc, acc1, ck, 0, min(osteps - c * 16, 16), Xs);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc[q] += acc1[q];
         if (lng) {  // merge the four DPP rows
-            acc.x += __shfl_xor(acc.x, 16); acc.y += __shfl_xor(acc.y, 16);
-            acc.z += __shfl_xor(acc.z, 16); acc.w += __shfl_xor(acc.w, 16);
-            acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32);
-            acc.z += __shfl_xor(acc.z, 32); acc.w += __shfl_xor(acc.w, 32);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+                acc[q] += __shfl_xor(acc[q], 16);
+                acc[q] += __shfl_xor(acc[q], 32);
+            }
         }
-        row_epilogue<DUAL, EPI, 4>(a, ri.x, lane, ri.x >= 0 && (!lng || g == 0), 8, kp, wtot, gcol, cl, right, cur.pre,
-                                   lc, acc, wloss);
+        const bool owner = valid && (!lng || g == 0);
+        row_epilogue<VEC, DUAL, EPI>(a, valid ? ri.x : 0, lane, owner, 8, cl, right, pre, lc, acc,
+                                     outs ? outs + static_cast<int64_t>(valid ? ri.x : 0) * RW : nullptr, 0, wloss);
         cur = nxt;
         nxt = nn;
     }
 
     if (EPI == EPI_LAP_SINGLE || EPI == EPI_LAP_DUAL) {
-        __shared__ double wl[TILED_WAVES];
+        __shared__ double wl[WIN_MAX_THREADS / 64];
         wloss = wave_sum(wloss);
         if (lane == 0) wl[wave] = wloss;
         __syncthreads();
         if (threadIdx.x == 0) {
             double t = 0.0;
-            for (int w = 0; w < TILED_WAVES; ++w) t += wl[w];
+            for (int w = 0; w < nwaves; ++w) t += wl[w];
             a.loss_part[blockIdx.x] = t;
         }
     }
 }
 
 // ------------------------------------------------------------------ small kernels of the Laplacian pass
-// X = [Y/sqrt(d) | Y/(sqrt(d) rho)] (zero padded to KP columns per half) and the block
-// partial column sums V^T Yn (3 rows) and U^T X2 (3 rows).
+// X = [Y/sqrt(d) | Y/(sqrt(d) rho)] (zero padded to KP columns per half) and the block partial column
+// sums V^T Yn (3 rows) and U^T X2 (3 rows).  Column c of half h of row r goes to
+// X[(c / hw) * plane + r * rw + h * hw + c % hw]: hw = KP, rw = row width, one slab for the row kernels;
+// hw columns of each half per slab for the windowed kernel.
 template <int KP, bool DUAL>
 __global__ __launch_bounds__(256) void lap_scale(int64_t m, int k, int64_t ldy, const float* __restrict__ Y,
-                                                 const float* __restrict__ rowc, float* __restrict__ X,
-                                                 float* __restrict__ colpart, int64_t rows_per_block) {
+                                                 const float* __restrict__ rowc, float* __restrict__ X, int hw, int rw,
+                                                 int64_t plane, float* __restrict__ colpart, int64_t rows_per_block) {
     constexpr int RG = 256 / KP;
-    constexpr int W = DUAL ? 2 * KP : KP;
     constexpr int NS = DUAL ? 6 : 3;
     const int col = threadIdx.x % KP, rg = threadIdx.x / KP;
     const int64_t base = blockIdx.x * rows_per_block;
     const int64_t end = min(m, base + rows_per_block);
+    const int64_t xoff = static_cast<int64_t>(col / hw) * plane + col % hw;
     float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (rg < RG) {
 #pragma unroll 4
-    for (int64_t r = base + rg; r < end; r += RG) {
-        const float4 rc0 = *reinterpret_cast<const float4*>(rowc + r * SPARC_ROWC);
-        const float4 rc1 = *reinterpret_cast<const float4*>(rowc + r * SPARC_ROWC + 4);
-        const float y = (col < k) ? Y[r * ldy + col] * rc0.w : 0.f;
-        X[r * W + col] = y;
-        s[0] += y;
-        s[1] += rc1.z * y;
-        s[2] += rc1.w * y;
-        if (DUAL) {
-            const float x2 = y * fabsf(rc0.x);
-            X[r * W + KP + col] = x2;
-            s[3] += x2;
-            s[4] += rc1.x * x2;
-            s[5] += rc1.y * x2;
+        for (int64_t r = base + rg; r < end; r += RG) {
+            const float4 rc0 = *reinterpret_cast<const float4*>(rowc + r * SPARC_ROWC);
+            const float4 rc1 = *reinterpret_cast<const float4*>(rowc + r * SPARC_ROWC + 4);
+            const float y = (col < k) ? Y[r * ldy + col] * rc0.w : 0.f;
+            X[xoff + r * rw] = y;
+            s[0] += y;
+            s[1] += rc1.z * y;
+            s[2] += rc1.w * y;
+            if (DUAL) {
+                const float x2 = y * fabsf(rc0.x);
+                X[xoff + r * rw + hw] = x2;
+                s[3] += x2;
+                s[4] += rc1.x * x2;
+                s[5] += rc1.y * x2;
+            }
         }
     }
     __shared__ float sm[RG][6][KP];
+    if (rg < RG) {
 #pragma unroll
-    for (int q = 0; q < NS; ++q) sm[rg][q][col] = s[q];
+        for (int q = 0; q < NS; ++q) sm[rg][q][col] = s[q];
+    }
     __syncthreads();
     if (rg == 0) {
 #pragma unroll
@@ -664,33 +647,33 @@ __global__ __launch_bounds__(256) void loss_finish(int64_t n, const double* __re
 }
 
 // ------------------------------------------------------------------ launch helpers
-// Optional timing of one kernel class with HIP events recorded on the launch stream.
+// Optional timing of one kernel class with HIP events recorded on the launch stream.  One profiling
+// session per process at a time; the mutex only keeps concurrent launches from corrupting the table.
 struct Profiler {
+    std::mutex mu;
     int epi = -1;                 // which epilogue class is timed
     std::vector<hipEvent_t> ev;   // start/stop pairs
     size_t used = 0;
     int64_t launches = 0;         // kernel launches covered by the pairs
-    int depth = 0;                // > 0 inside a bracket: nested brackets do not record
 } g_prof;
 
 // One start/stop pair around `count` back-to-back launches of the timed class (the two inner passes of
 // the Laplacian chain share a pair, which halves the share of the event overhead in the average).
 struct Timed {
-    bool on;
+    size_t slot = SIZE_MAX;
     hipStream_t s;
-    int count;
-    Timed(int epi, hipStream_t stream, int count_ = 1)
-        : on(g_prof.depth == 0 && g_prof.epi == epi && g_prof.used + 2 <= g_prof.ev.size()), s(stream), count(count_) {
-        ++g_prof.depth;
-        if (on) (void)hipEventRecord(g_prof.ev[g_prof.used], s);
-    }
-    ~Timed() {
-        --g_prof.depth;
-        if (on) {
-            (void)hipEventRecord(g_prof.ev[g_prof.used + 1], s);
+    Timed(int epi, hipStream_t stream, int count) : s(stream) {
+        if (g_prof.epi < 0) return;  // no session: no lock on the launch path
+        std::lock_guard<std::mutex> lock(g_prof.mu);
+        if (g_prof.epi == epi && g_prof.used + 2 <= g_prof.ev.size()) {
+            slot = g_prof.used;
             g_prof.used += 2;
             g_prof.launches += count;
+            (void)hipEventRecord(g_prof.ev[slot], s);
         }
+    }
+    ~Timed() {
+        if (slot != SIZE_MAX) (void)hipEventRecord(g_prof.ev[slot + 1], s);
     }
 };
 
@@ -699,43 +682,43 @@ int launch_rows(const SpmmArgs& a, hipStream_t stream) {
     const int64_t nb = (a.m + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
     if (nb <= 0) return SPARC_OK;
     if (nb > 0x7fffffffLL) return SPARC_ERR_ARG;
-    {
-        Timed t(EPI, stream);
-        hipLaunchKernelGGL((spmm_rows<LR, DUAL, EPI>), dim3(static_cast<unsigned>(nb)), dim3(256), 0, stream, a);
-    }
+    hipLaunchKernelGGL((spmm_rows<LR, DUAL, EPI>), dim3(static_cast<unsigned>(nb)), dim3(256), 0, stream, a);
     SPARC_CHECK_LAUNCH();
     return SPARC_OK;
 }
 
-template <bool DUAL, int EPI>
-int launch_tiled(const SpmmArgs& a, hipStream_t stream) {
-    const size_t lds = static_cast<size_t>(a.tile_rows) * 16 * sizeof(float4);
-    if (a.ndesc <= 0) return SPARC_OK;
-    if (lds > SPARC_TILE_LDS_BYTES) return SPARC_ERR_ARG;
-    static bool configured = false;  // per instantiation: allow the large dynamic LDS allocation
-    if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_tiled<DUAL, EPI>),
+// Per device and per instantiation: allow the large dynamic LDS allocation.
+template <int VEC, bool DUAL, int EPI>
+int configure_win() {
+    static std::mutex mu;
+    static bool done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SPARC_ERR_LAUNCH;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!done[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_win<VEC, DUAL, EPI>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, SPARC_TILE_LDS_BYTES) != hipSuccess)
             return SPARC_ERR_LAUNCH;
-        configured = true;
+        done[dev] = true;
     }
-    {
-        SpmmArgs b = a;
-        static const int dbg = [] {  // developer switch for kernel ablation timings, read once
-            const char* e = getenv("SPARC_DBG");
-            return e ? atoi(e) : 0;
-        }();
-        b.dbg = dbg;
-        Timed t(EPI, stream);
-        hipLaunchKernelGGL((spmm_tiled<DUAL, EPI>), dim3(static_cast<unsigned>(a.ndesc)), dim3(TILED_THREADS), lds, stream, b);
-    }
+    return SPARC_OK;
+}
+
+template <int VEC, bool DUAL, int EPI>
+int launch_win(const SpmmArgs& a, hipStream_t stream) {
+    if (a.ndesc <= 0) return SPARC_OK;
+    const size_t lds = static_cast<size_t>(a.tile_rows) * 64 * VEC;
+    if (lds > SPARC_TILE_LDS_BYTES || a.threads < 64 || a.threads > WIN_MAX_THREADS || a.threads % 64) return SPARC_ERR_ARG;
+    const int rc = configure_win<VEC, DUAL, EPI>();
+    if (rc) return rc;
+    hipLaunchKernelGGL((spmm_win<VEC, DUAL, EPI>), dim3(static_cast<unsigned>(a.ndesc)), dim3(a.threads), lds, stream, a);
     SPARC_CHECK_LAUNCH();
     return SPARC_OK;
 }
 
 template <int EPI>
 int launch_single(int width, const SpmmArgs& a, hipStream_t s) {
-    if (a.desc && width == 64) return launch_tiled<false, EPI>(a, s);
+    if (a.desc) return a.vec == 2 ? launch_win<2, false, EPI>(a, s) : launch_win<4, false, EPI>(a, s);
     switch (width) {
         case 16: return launch_rows<4, false, EPI>(a, s);
         case 32: return launch_rows<8, false, EPI>(a, s);
@@ -747,7 +730,7 @@ int launch_single(int width, const SpmmArgs& a, hipStream_t s) {
 
 template <int EPI>
 int launch_dual(int kp, const SpmmArgs& a, hipStream_t s) {
-    if (a.desc && (kp == 32 || kp == 64)) return launch_tiled<true, EPI>(a, s);
+    if (a.desc) return a.vec == 2 ? launch_win<2, true, EPI>(a, s) : launch_win<4, true, EPI>(a, s);
     switch (kp) {
         case 16: return launch_rows<8, true, EPI>(a, s);
         case 32: return launch_rows<16, true, EPI>(a, s);
@@ -756,45 +739,66 @@ int launch_dual(int kp, const SpmmArgs& a, hipStream_t s) {
     return SPARC_ERR_ARG;
 }
 
-int padded_k(int k) { return k <= 16 ? 16 : (k <= 32 ? 32 : 64); }
+// Checks a tiling against the pass it is used for and fills the SpmmArgs fields.  dual: the training pass
+// ([A half | A^T half], kp columns each); otherwise kp columns in all.
+int set_tiling(SpmmArgs& a, const sparc_tiling_t* t, int64_t m, bool dual, int kp) {
+    a.desc = nullptr;
+    a.rowinfo = nullptr;
+    a.ndesc = 0;
+    if (!t) return SPARC_OK;
+    const int hw = dual ? 8 * t->vec : 16 * t->vec;   // columns of a half (dual) or of the row (single) per slab
+    if (!t->buf || t->ndesc <= 0 || (t->vec != 2 && t->vec != 4) || t->rows <= 0 ||
+        static_cast<size_t>(t->rows) * 64 * t->vec > SPARC_TILE_LDS_BYTES || (t->dual != 0) != dual || t->kp != kp ||
+        kp % hw != 0 || t->threads < 64 || t->threads > WIN_MAX_THREADS || t->threads % 64)
+        return SPARC_ERR_ARG;
+    a.desc = t->buf;
+    a.rowinfo = t->buf + static_cast<int64_t>(t->ndesc) * 8;  // the row records follow the descriptors
+    a.ndesc = t->ndesc;
+    a.tile_rows = t->rows;
+    a.vec = t->vec;
+    a.threads = t->threads;
+    a.plane = m * 16 * t->vec;
+    return SPARC_OK;
+}
 
 }  // namespace
 
 int64_t sparc_rows_blocks(int64_t m) { return (m + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK; }
 
 int sparc_spmm_launch(int epi, int width, const SpmmArgs& a, hipStream_t stream) {
+    Timed t(epi, stream, 1);
     switch (epi) {
         case EPI_STORE: return launch_single<EPI_STORE>(width, a, stream);
         case EPI_ADD_X0: return launch_single<EPI_ADD_X0>(width, a, stream);
-        case EPI_ADD_IDENT: return width == 64 ? launch_single<EPI_ADD_IDENT>(64, a, stream) : SPARC_ERR_ARG;
-        case EPI_PREP_ACC: return width == 64 ? launch_single<EPI_PREP_ACC>(64, a, stream) : SPARC_ERR_ARG;
+        case EPI_ADD_IDENT: return width == 64 && !a.desc ? launch_single<EPI_ADD_IDENT>(64, a, stream) : SPARC_ERR_ARG;
+        case EPI_PREP_ACC: return width == 64 && !a.desc ? launch_single<EPI_PREP_ACC>(64, a, stream) : SPARC_ERR_ARG;
     }
     return SPARC_ERR_ARG;
 }
 
 extern "C" int sparc_profile_begin(int epilogue, int max_launches) {
     if (max_launches < 0 || epilogue < 0 || epilogue > EPI_PREP_ACC) return SPARC_ERR_ARG;
+    std::lock_guard<std::mutex> lock(g_prof.mu);
     for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
     g_prof.ev.assign(static_cast<size_t>(max_launches) * 2, nullptr);
     for (auto& e : g_prof.ev)
         if (hipEventCreate(&e) != hipSuccess) return SPARC_ERR_LAUNCH;
     g_prof.used = 0;
     g_prof.launches = 0;
-    g_prof.depth = 0;
     g_prof.epi = epilogue;
     return SPARC_OK;
 }
 
 extern "C" int sparc_profile_end(double* total_ms, int64_t* launches) {
+    std::lock_guard<std::mutex> lock(g_prof.mu);
     double total = 0.0;
-    int64_t n = 0;
     for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
         float ms = 0.f;
         if (hipEventSynchronize(g_prof.ev[i + 1]) != hipSuccess) return SPARC_ERR_LAUNCH;
         if (hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]) != hipSuccess) return SPARC_ERR_LAUNCH;
         total += ms;
     }
-    n = g_prof.launches;
+    const int64_t n = g_prof.launches;
     for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
     g_prof.ev.clear();
     g_prof.used = 0;
@@ -804,51 +808,33 @@ extern "C" int sparc_profile_end(double* total_ms, int64_t* launches) {
     return SPARC_OK;
 }
 
-namespace {
-// Checks the tiling arguments that can be checked on the host; fills the SpmmArgs fields.
-int set_tiles(SpmmArgs& a, const int32_t* tiles, int ntiles, int tile_rows, int kp, int wtot) {
-    a.kp = kp;
-    a.wtot = wtot;
-    a.desc = nullptr;
-    a.rowinfo = nullptr;
-    a.ndesc = 0;
-    a.tile_rows = 0;
-    if (!tiles) return SPARC_OK;
-    if (ntiles <= 0 || tile_rows <= 0 || tile_rows > SPARC_TILE_MAX_ROWS) return SPARC_ERR_ARG;
-    a.desc = tiles;
-    a.rowinfo = tiles + static_cast<int64_t>(ntiles) * 8;  // the row records follow the descriptors
-    a.ndesc = ntiles;
-    a.tile_rows = tile_rows;
-    return SPARC_OK;
-}
-}  // namespace
-
 extern "C" int sparc_spmm(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* colidx, const float* val,
-                          int width, const float* X, const float* X0, float* Z, const int32_t* tiles, int ntiles,
-                          int tile_rows, int val_is_mirrored, sparc_stream_t stream) {
+                          int width, const float* X, const float* X0, float* Z, const sparc_tiling_t* tiling,
+                          sparc_stream_t stream) {
     if (m < 0 || nnz < 0 || !rowptr || (nnz > 0 && (!colidx || !val)) || !X || !Z) return SPARC_ERR_ARG;
     SpmmArgs a = {};
     a.m = m; a.rowptr = rowptr; a.col = colidx; a.val = val; a.valT = val;
     a.Xg = X; a.X0 = X0; a.out = Z;
-    a.rec_mirrored = val_is_mirrored != 0;
-    if (tiles && width != 64) return SPARC_ERR_ARG;
-    const int rc = set_tiles(a, tiles, ntiles, tile_rows, width, width);
+    a.kp = width;
+    // a tiled plain product works on one slab: the row-major operand is the slab
+    if (tiling && (tiling->kp != width || width != 16 * tiling->vec)) return SPARC_ERR_ARG;
+    const int rc = set_tiling(a, tiling, m, false, width);
     if (rc) return rc;
     return sparc_spmm_launch(X0 ? EPI_ADD_X0 : EPI_STORE, width, a, stream);
 }
 
 namespace {
 constexpr int SCALE_MAX_BLOCKS = 256;
+// Columns per half: the windowed kernel takes multiples of 16, the row kernels 16, 32 or 64.
+int padded_k(int k, bool tiled) { return tiled ? (k + 15) / 16 * 16 : (k <= 16 ? 16 : (k <= 32 ? 32 : 64)); }
+
 struct LapPlan {
-    int kp, W;
     int64_t nscale, rows_per_block, nloss;
     size_t bytes;
 };
-LapPlan lap_plan(int64_t m, int k, int ntiles) {
+LapPlan lap_plan(int64_t m, int kp, int ntiles) {
     LapPlan p;
-    p.kp = padded_k(k);
-    p.W = 2 * p.kp;
-    const int rg = 256 / p.kp;
+    const int rg = 256 / kp;
     int64_t nb = (m + 63) / 64;
     if (nb > SCALE_MAX_BLOCKS) nb = SCALE_MAX_BLOCKS;
     if (nb < 1) nb = 1;
@@ -860,8 +846,8 @@ LapPlan lap_plan(int64_t m, int k, int ntiles) {
     if (p.nscale < 1) p.nscale = 1;
     p.nloss = sparc_rows_blocks(m);
     if (ntiles > p.nloss) p.nloss = ntiles;
-    p.bytes = 3 * sparc_align_up(static_cast<size_t>(m) * p.W * sizeof(float)) +
-              sparc_align_up(static_cast<size_t>(SCALE_MAX_BLOCKS) * 6 * p.kp * sizeof(float)) +
+    p.bytes = 3 * sparc_align_up(static_cast<size_t>(m) * 2 * kp * sizeof(float)) +
+              sparc_align_up(static_cast<size_t>(SCALE_MAX_BLOCKS) * 6 * kp * sizeof(float)) +
               sparc_align_up((6 * SPARC_MAX_K + 16) * sizeof(float)) +
               sparc_align_up(static_cast<size_t>(p.nloss > 0 ? p.nloss : 1) * sizeof(double));
     return p;
@@ -870,48 +856,56 @@ LapPlan lap_plan(int64_t m, int k, int ntiles) {
 
 extern "C" size_t sparc_lap_workspace_bytes(int64_t m, int k, int ntiles) {
     if (m < 0 || k < 1 || k > SPARC_MAX_K || ntiles < 0) return 0;
-    return lap_plan(m, k, ntiles).bytes;
+    return lap_plan(m, SPARC_MAX_K, ntiles).bytes;   // covers the column padding of every kernel variant
 }
 
 extern "C" int sparc_lap_fwd(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* colidx, const float* val,
                              const float* valT, const float* rowc, const double* coupling, int k, int64_t ldy,
-                             const float* Y, double* loss, float* gradY, const int32_t* tiles, int ntiles,
-                             int tile_rows, void* ws, size_t ws_bytes, sparc_stream_t stream) {
+                             const float* Y, double* loss, float* gradY, const sparc_tiling_t* tiling,
+                             void* ws, size_t ws_bytes, sparc_stream_t stream) {
     if (m <= 0 || nnz < 0 || k < 1 || k > SPARC_MAX_K || ldy < k || !rowptr || !rowc || !coupling || !Y || !loss ||
-        (nnz > 0 && (!colidx || !val)) || ntiles < 0)
+        (nnz > 0 && (!colidx || !val)))
         return SPARC_ERR_ARG;
-    const LapPlan p = lap_plan(m, k, tiles ? ntiles : 0);
-    WsCarver c(ws, ws_bytes);
     const bool dual = gradY != nullptr;
-    const int W = dual ? p.W : p.kp;
-    float* X = c.take<float>(static_cast<size_t>(m) * p.W);
-    float* P1 = c.take<float>(static_cast<size_t>(m) * p.W);
-    float* P2 = c.take<float>(static_cast<size_t>(m) * p.W);
-    float* colpart = c.take<float>(static_cast<size_t>(SCALE_MAX_BLOCKS) * 6 * p.kp);
+    const bool tiled = tiling != nullptr;
+    const int kp = tiled ? tiling->kp : padded_k(k, false);
+    if (kp < k || kp > SPARC_MAX_K || kp % 16) return SPARC_ERR_ARG;
+    const LapPlan p = lap_plan(m, kp, tiled ? tiling->ndesc : 0);
+    if (p.bytes > sparc_lap_workspace_bytes(m, k, tiled ? tiling->ndesc : 0)) return SPARC_ERR_ARG;
+    WsCarver c(ws, ws_bytes);
+    const int W = dual ? 2 * kp : kp;
+    float* X = c.take<float>(static_cast<size_t>(m) * 2 * kp);
+    float* P1 = c.take<float>(static_cast<size_t>(m) * 2 * kp);
+    float* P2 = c.take<float>(static_cast<size_t>(m) * 2 * kp);
+    float* colpart = c.take<float>(static_cast<size_t>(SCALE_MAX_BLOCKS) * 6 * kp);
     float* M12 = c.take<float>(6 * SPARC_MAX_K + 16);
     double* loss_part = c.take<double>(static_cast<size_t>(p.nloss));
     if (!ws || !c.ok()) return SPARC_ERR_WS;
 
     SpmmArgs a = {};
     a.m = m; a.rowptr = rowptr; a.col = colidx; a.val = val; a.valT = valT ? valT : val;
-    a.rowc = rowc; a.M12 = M12; a.loss_part = loss_part; a.gradY = gradY; a.ldy = ldy; a.k = k;
+    a.rowc = rowc; a.M12 = M12; a.loss_part = loss_part; a.gradY = gradY; a.ldy = ldy; a.k = k; a.kp = kp;
     a.inv_m = static_cast<float>(1.0 / static_cast<double>(m));
-    // the tiled kernel covers 64-float single rows and 32- or 64-float halves of dual rows
-    const bool tiled = tiles && (dual ? p.kp >= 32 : p.kp == 64);
-    int rcode = set_tiles(a, tiled ? tiles : nullptr, ntiles, tile_rows, p.kp, W);
+    int rcode = set_tiling(a, tiling, m, dual, kp);
     if (rcode) return rcode;
-    const int64_t nparts = tiled ? ntiles : sparc_rows_blocks(m);
+    const int64_t nparts = tiled ? tiling->ndesc : sparc_rows_blocks(m);
+    // operand layout: one slab of full rows for the row kernels, slabs of hw columns per half otherwise
+    const int hw = tiled ? (dual ? 8 : 16) * tiling->vec : kp;
+    const int rw = tiled ? 16 * tiling->vec : W;
+    const int64_t plane = tiled ? a.plane : 0;
 
     const dim3 gs(static_cast<unsigned>(p.nscale)), bs(256);
 #define SPARC_SCALE(KP)                                                                                              \
     if (dual)                                                                                                        \
-        hipLaunchKernelGGL((lap_scale<KP, true>), gs, bs, 0, stream, m, k, ldy, Y, rowc, X, colpart, p.rows_per_block); \
+        hipLaunchKernelGGL((lap_scale<KP, true>), gs, bs, 0, stream, m, k, ldy, Y, rowc, X, hw, rw, plane, colpart,   \
+                           p.rows_per_block);                                                                        \
     else                                                                                                             \
-        hipLaunchKernelGGL((lap_scale<KP, false>), gs, bs, 0, stream, m, k, ldy, Y, rowc, X, colpart, p.rows_per_block);
-    if (p.kp == 16) { SPARC_SCALE(16) } else if (p.kp == 32) { SPARC_SCALE(32) } else { SPARC_SCALE(64) }
+        hipLaunchKernelGGL((lap_scale<KP, false>), gs, bs, 0, stream, m, k, ldy, Y, rowc, X, hw, rw, plane, colpart,  \
+                           p.rows_per_block);
+    if (kp == 16) { SPARC_SCALE(16) } else if (kp == 32) { SPARC_SCALE(32) } else if (kp == 48) { SPARC_SCALE(48) } else { SPARC_SCALE(64) }
 #undef SPARC_SCALE
     SPARC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(lap_colsum_finish, dim3(1), dim3(6 * p.kp), 0, stream, p.kp, static_cast<int>(p.nscale), dual,
+    hipLaunchKernelGGL(lap_colsum_finish, dim3(1), dim3(6 * kp), 0, stream, kp, static_cast<int>(p.nscale), dual,
                        colpart, coupling, M12);
     SPARC_CHECK_LAUNCH();
 
@@ -920,15 +914,18 @@ extern "C" int sparc_lap_fwd(int64_t m, int64_t nnz, const int64_t* rowptr, cons
     {
         Timed both(EPI_ADD_X0, stream, 2);   // the two inner passes, back to back
         a.Xg = X; a.out = P1;
-        rcode = dual ? launch_dual<EPI_ADD_X0>(p.kp, a, stream) : launch_single<EPI_ADD_X0>(W, a, stream);
+        rcode = dual ? launch_dual<EPI_ADD_X0>(kp, a, stream) : launch_single<EPI_ADD_X0>(W, a, stream);
         if (rcode) return rcode;
         a.Xg = P1; a.out = P2;
-        rcode = dual ? launch_dual<EPI_ADD_X0>(p.kp, a, stream) : launch_single<EPI_ADD_X0>(W, a, stream);
+        rcode = dual ? launch_dual<EPI_ADD_X0>(kp, a, stream) : launch_single<EPI_ADD_X0>(W, a, stream);
         if (rcode) return rcode;
     }
     a.Xg = P2; a.out = nullptr;
-    rcode = dual ? launch_dual<EPI_LAP_DUAL>(p.kp, a, stream) : launch_single<EPI_LAP_SINGLE>(W, a, stream);
-    if (rcode) return rcode;
+    {
+        Timed last(dual ? EPI_LAP_DUAL : EPI_LAP_SINGLE, stream, 1);
+        rcode = dual ? launch_dual<EPI_LAP_DUAL>(kp, a, stream) : launch_single<EPI_LAP_SINGLE>(W, a, stream);
+        if (rcode) return rcode;
+    }
     hipLaunchKernelGGL(loss_finish, dim3(1), dim3(256), 0, stream, nparts, loss_part, 1.0 / static_cast<double>(m), loss);
     SPARC_CHECK_LAUNCH();
     return SPARC_OK;

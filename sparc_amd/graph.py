@@ -16,14 +16,16 @@ from . import _lib
 from ._lib import check, lib
 
 EPS_BACKGROUND = 1e-6  # src/SpectralTrainer.py:288
-TILE_MAX_ROWS = 512     # SPARC_TILE_MAX_ROWS: rows of one LDS window (256 bytes each)
-TILE_LONG_ROW = 64       # SPARC_TILE_LONG_ROW: longer rows get a whole wavefront
-TILE_MAX_OUTSIDE = 2    # SPARC_TILE_MAX_OUTSIDE: entries of a row outside its window that ride in the row record
-TILE_TARGET_WGS = 256   # one workgroup per CU
+TILE_LDS_BYTES = 128 * 1024   # LDS budget of one window (rows * 64 * vec bytes)
+TILE_MAX_ROWS = 512           # rows of one window
+TILE_LONG_ROW = 64            # SPARC_TILE_LONG_ROW: longer rows get a whole wavefront
+TILE_MAX_RUN = 65535          # entries of one row before / behind its window
+TILE_MAX_OUTSIDE_SHARE = 0.5  # a batch with a larger share of its entries outside the windows is not tiled
+N_CU = 256
 
 
 def plan_windows(m: int, cluster_sizes=None, max_rows: int = TILE_MAX_ROWS):
-    """Row windows [begin, end) for the LDS-tiled kernel: consecutive clusters are merged while
+    """Row windows [begin, end) for the windowed kernel: consecutive clusters are merged while
     they fit one window, clusters larger than a window are split evenly; without cluster sizes
     the rows are cut into equal windows."""
     if cluster_sizes is None or int(np.sum(cluster_sizes)) != m:
@@ -52,52 +54,35 @@ def plan_windows(m: int, cluster_sizes=None, max_rows: int = TILE_MAX_ROWS):
     return [(a, b) for a, b in wins if b > a]
 
 
-def plan_tiles(windows, lo: np.ndarray, hi: np.ndarray, n_out: np.ndarray, out_rec: np.ndarray, n_slabs: int,
-               target_wgs: int = TILE_TARGET_WGS):
-    """The tiling buffer of the LDS-tiled kernel (layout: include/sparc_hip.h): descriptors and row
-    records.  [lo, hi) are the positions of every row's in-window entries, n_out the number of
-    its other entries and out_rec int32[m][6] = {col0, col1, val0, valT0, val1, valT1} (float
-    bits) the first two of them.  Every window's rows are sorted by in-window length (longest
-    first) and dealt round-robin to J parts so that windows x slabs x J fills the chip with
-    equal work; rows with more than TILE_MAX_OUTSIDE outside entries go to slab = -1 workgroups,
-    which gather from global memory."""
+def plan_tiles(windows, p0: np.ndarray, lo: np.ndarray, hi: np.ndarray, p1: np.ndarray, n_slabs: int,
+               threads: int = 512, target_wgs: int = 2 * N_CU):
+    """The tiling buffer of the windowed kernel (layout: include/sparc_hip.h): descriptors int32[.][8] and
+    row records int32[m][4].  Row i stores its entries at [p0, p1); those whose column lies in the
+    row's window are [lo, hi).  Every window's rows are sorted by in-window length (longest first)
+    and dealt round-robin to J parts so that windows x slabs x J fills the chip with equal work."""
     nw = len(windows)
     J = max(1, target_wgs // max(nw * n_slabs, 1))
     desc, recs = [], []
     q = 0
     length = hi - lo
-    tiled_ok = n_out <= TILE_MAX_OUTSIDE
-
-    def records(rows):
-        z = np.zeros_like(rows)
-        head = np.stack([rows, lo[rows], hi[rows], np.minimum(n_out[rows], TILE_MAX_OUTSIDE)], axis=1)
-        return np.concatenate([head, out_rec[rows], np.stack([z, z], axis=1)], axis=1)
+    packed = ((lo - p0) << 16) | (p1 - hi)
+    min_rows = threads // 16                      # one row per 16-lane group of the workgroup
 
     for (a, b) in windows:
         rows = np.arange(a, b)
-        rows = rows[tiled_ok[a:b]]
-        if len(rows) == 0:
-            continue
         order = rows[np.argsort(-length[rows], kind="stable")]
-        parts = max(1, min(J, (len(order) + 63) // 64))   # at least one row per 16-lane group of the workgroup
+        parts = max(1, min(J, (len(order) + min_rows - 1) // min_rows))
         for j in range(parts):
             mine = order[j::parts]
             if len(mine) == 0:
                 continue
-            recs.append(records(mine))
+            recs.append(np.stack([mine, p0[mine], length[mine], packed[mine]], axis=1))
             n_long = int((length[mine] > TILE_LONG_ROW).sum())
             for s_ in range(n_slabs):
                 desc.append((q, q + len(mine), a, b, s_, n_long, 0, 0))
             q += len(mine)
-    loose = np.nonzero(~tiled_ok)[0]
-    if len(loose):
-        for part in np.array_split(loose, max(1, (len(loose) + 15) // 16)):
-            if len(part):
-                recs.append(records(part))
-                desc.append((q, q + len(part), 0, 0, -1, 0, 0, 0))
-                q += len(part)
     desc = np.asarray(_xcd_align(desc), dtype=np.int32).reshape(-1, 8)
-    recs = np.concatenate(recs, axis=0).astype(np.int32) if recs else np.zeros((0, 12), np.int32)
+    recs = np.concatenate(recs, axis=0).astype(np.int32) if recs else np.zeros((0, 4), np.int32)
     return desc, recs
 
 
@@ -114,7 +99,7 @@ def _xcd_align(desc):
         return desc
     groups = {}
     for d in desc:
-        key = (d[2], d[3]) if d[4] >= 0 else ("loose", d[0])
+        key = (d[2], d[3])
         groups.setdefault(key, []).append(d)
     bins = [[] for _ in range(N_XCD)]
     load = [0] * N_XCD
@@ -238,9 +223,8 @@ class ClusterBatch:
         return self
 
     def _in_window_ranges(self):
-        """Per row: positions [lo, hi) of its entries whose column lies in the row's window, the
-        number of its other entries and the first two of those (column, val, valT as float bits);
-        computed once on the device, kept on the host."""
+        """Per row: its stored entries [p0, p1) and the positions [lo, hi) of those whose column lies in
+        the row's window; computed once on the device, kept on the host (int64 arrays)."""
         if self._window_ranges is None:
             m, dev = self.m, self.device
             wb = torch.empty(m, dtype=torch.int64, device=dev)
@@ -254,45 +238,64 @@ class ClusterBatch:
             base = torch.arange(m, device=dev, dtype=torch.int64) * m
             lo = torch.searchsorted(keys, base + wb)
             hi = torch.searchsorted(keys, base + we)
-            n_out = (lo - p0) + (p1 - hi)
-            # positions of the first two outside entries: before the window first, then after it
-            nb = lo - p0
-            pos0 = torch.where(nb > 0, p0, hi)
-            pos1 = torch.where(nb > 1, p0 + 1, torch.where(nb == 1, hi, hi + 1))
-            last = max(self.nnz - 1, 0)
-            pos0c, pos1c = pos0.clamp(0, last), pos1.clamp(0, last)
-            valT = self.valT if self.valT is not None else self.val
-            bits = lambda t: t.view(torch.int32).to(torch.int64)
-            has0, has1 = n_out > 0, n_out > 1
-            zero = torch.zeros_like(lo)
-            rec = torch.stack([torch.where(has0, self.colidx[pos0c].to(torch.int64), zero),
-                               torch.where(has1, self.colidx[pos1c].to(torch.int64), zero),
-                               torch.where(has0, bits(self.val[pos0c]), zero),
-                               torch.where(has0, bits(valT[pos0c]), zero),
-                               torch.where(has1, bits(self.val[pos1c]), zero),
-                               torch.where(has1, bits(valT[pos1c]), zero)], dim=1) if self.nnz else \
-                torch.zeros(m, 6, dtype=torch.int64, device=dev)
-            self._window_ranges = tuple(t.cpu().numpy() for t in (lo, hi, n_out, rec))
+            self._window_ranges = tuple(t.cpu().numpy() for t in (p0, lo, hi, p1))
         return self._window_ranges
 
-    def tiles(self, n_slabs: int):
-        """(device tiling buffer, descriptor count, largest window) for the tiled kernel, cached per slab count."""
-        hit = self._tiles.get(n_slabs)
-        if hit is None:
-            if self.nnz >= 2 ** 31:
-                raise ValueError("the tiled kernel needs nnz < 2^31")
-            lo, hi, n_out, out_rec = self._in_window_ranges()
-            desc, recs = plan_tiles(self._windows, lo, hi, n_out, out_rec, n_slabs)
-            assert recs.shape[0] == self.m
-            n_loose = int(sum(d[1] - d[0] for d in desc if d[4] < 0))
-            if n_loose > 0.05 * self.m:   # too many rows reach outside their window: tiling does not pay
-                self._tiles[n_slabs] = (None, 0, 0)
-                return self._tiles[n_slabs]
-            buf = np.concatenate([desc.ravel(), recs.ravel()]).astype(np.int32)
-            rows = max(b - a for a, b in self._windows)
-            hit = (torch.from_numpy(buf).to(self.device), int(desc.shape[0]), int(rows))
-            self._tiles[n_slabs] = hit
-        return hit
+    # ---- tiling policy ---------------------------------------------------------------------
+    tile_vec = 2            # floats per lane of the windowed kernel (2: 32-float slabs, 4: 64-float slabs)
+    tile_threads = None     # workgroup size (None: 512 for vec 2, 1024 for vec 4)
+    tile_target_wgs = None  # workgroups to aim for (None: two per CU for vec 2, one for vec 4)
+
+    @classmethod
+    def tile_geometry(cls, k: int, training: bool):
+        """(vec, kp, n_slabs) of the windowed kernel for spectral dimension k, or None when the pass
+        runs on the row kernel.  Training pass: slabs of 8 vec columns of each half, kp = k rounded up to
+        that; forward-only pass: slabs of 16 vec columns, for k > 16."""
+        if not cls.use_tiles:
+            return None
+        vec = cls.tile_vec
+        if training:
+            hw = 8 * vec
+        else:
+            if k <= 16:
+                return None
+            hw = 16 * vec
+        kp = -(-k // hw) * hw
+        return vec, kp, kp // hw
+
+    def tiling(self, k: int, training: bool):
+        """The _lib.Tiling of this batch for the given pass (cached), or None: no windowed kernel for this
+        k, or too large a share of the batch's entries lies outside the windows."""
+        geo = self.tile_geometry(k, training)
+        if geo is None:
+            return None
+        vec, kp, n_slabs = geo
+        threads = self.tile_threads or (512 if vec == 2 else 1024)
+        target = self.tile_target_wgs or (2 * N_CU if vec == 2 else N_CU)
+        key = (vec, kp, bool(training), threads, target)
+        if key not in self._tiles:
+            self._tiles[key] = self._plan(vec, kp, n_slabs, bool(training), threads, target)
+        return self._tiles[key]
+
+    def _plan(self, vec, kp, n_slabs, dual, threads, target):
+        if self.nnz >= 2 ** 31 or self.m == 0:
+            return None
+        rows = max(b - a for a, b in self._windows)
+        if rows * 64 * vec > TILE_LDS_BYTES:
+            return None
+        p0, lo, hi, p1 = self._in_window_ranges()
+        before, after = lo - p0, p1 - hi
+        if len(before) and (before.max() > TILE_MAX_RUN or after.max() > TILE_MAX_RUN):
+            return None
+        if (before.sum() + after.sum()) > TILE_MAX_OUTSIDE_SHARE * max(self.nnz, 1):
+            return None
+        desc, recs = plan_tiles(self._windows, p0, lo, hi, p1, n_slabs, threads, target)
+        assert recs.shape[0] == self.m
+        buf = torch.from_numpy(np.concatenate([desc.ravel(), recs.ravel()]).astype(np.int32)).to(self.device)
+        t = _lib.Tiling(buf.data_ptr(), int(desc.shape[0]), int(rows), vec, threads, kp, int(dual))
+        t.keep = buf             # the struct points into this tensor
+        t.desc = desc
+        return t
 
     def _prepare(self, eps):
         m, device = self.m, self.device
@@ -307,17 +310,9 @@ class ClusterBatch:
                                           _ptr(ws), nbytes, _stream()), "sparc_affinity_prep")
         self.d, self.cw, self.rho = vec[0], vec[1], vec[2]
 
-    @staticmethod
-    def train_slabs(k: int) -> int:
-        """Column slabs of the tiled training pass for spectral dimension k (0: the row kernel runs)."""
-        kp = 16 if k <= 16 else (32 if k <= 32 else 64)
-        return kp // 32
-
     def warm(self, k: int, training: bool = True):
         """Build the tiling for spectral dimension k now (it is otherwise built on first use)."""
-        kp = 16 if k <= 16 else (32 if k <= 32 else 64)
-        if self.use_tiles and ((training and kp >= 32) or (not training and kp == 64)):
-            self.tiles(kp // 32 if training else 1)
+        self.tiling(k, training)
         return self
 
     # ---- per-step work -------------------------------------------------------------------
@@ -336,11 +331,8 @@ class ClusterBatch:
             Y = Y.float().contiguous()
         loss = torch.empty((), dtype=torch.float64, device=self.device)
         grad = torch.empty_like(Y) if want_grad else None
-        kp = 16 if k <= 16 else (32 if k <= 32 else 64)
-        tiles, ntiles, tile_rows = None, 0, 0
-        if self.use_tiles and ((want_grad and kp >= 32) or (not want_grad and kp == 64)):
-            tiles, ntiles, tile_rows = self.tiles(kp // 32 if want_grad else 1)
-        nbytes = lib.sparc_lap_workspace_bytes(self.m, k, ntiles)
+        t = self.tiling(k, want_grad)
+        nbytes = lib.sparc_lap_workspace_bytes(self.m, k, t.ndesc if t is not None else 0)
         ws = Workspace.get(nbytes, self.device)
         with torch.cuda.device(self.device):
             rowc = self.rowc
@@ -351,21 +343,33 @@ class ClusterBatch:
                 rowc = self._rowc_plain
             check(lib.sparc_lap_fwd(self.m, self.nnz, _ptr(self.rowptr), _ptr(self.colidx), _ptr(self.val),
                                     _ptr(self.valT), _ptr(rowc), _ptr(self.coupling), k, k, _ptr(Y), _ptr(loss),
-                                    _ptr(grad), _ptr(tiles), ntiles, tile_rows, _ptr(ws), nbytes, _stream()),
+                                    _ptr(grad), ctypes.byref(t) if t is not None else None, _ptr(ws), nbytes, _stream()),
                   "sparc_lap_fwd")
         return loss, grad
 
     def spmm(self, X: torch.Tensor, add: torch.Tensor | None = None, transpose: bool = False,
              tiled: bool = False) -> torch.Tensor:
-        """Z = A X (+ add); width of X must be 16, 32, 64 or 128 (tiled: 64)."""
+        """Z = A X (+ add); width of X must be 16, 32, 64 or 128 (tiled: 32 or 64, one slab of the windowed
+        kernel)."""
         X = X.contiguous()
         Z = torch.empty_like(X)
         v = self.val if (not transpose or self.valT is None) else self.valT
-        tiles, ntiles, tile_rows = self.tiles(1) if tiled else (None, 0, 0)
+        width = int(X.shape[1])
+        t = None
+        if tiled:
+            if width not in (32, 64):
+                raise ValueError("the windowed kernel takes a plain product of width 32 or 64")
+            key = ("spmm", width)
+            if key not in self._tiles:
+                self._tiles[key] = self._plan(width // 16, width, 1, False, 512 if width == 32 else 1024,
+                                              2 * N_CU if width == 32 else N_CU)
+            t = self._tiles[key]
+            if t is None:
+                raise ValueError("this batch has no tiling")
         with torch.cuda.device(self.device):
-            check(lib.sparc_spmm(self.m, self.nnz, _ptr(self.rowptr), _ptr(self.colidx), _ptr(v), int(X.shape[1]),
-                                 _ptr(X), _ptr(add), _ptr(Z), _ptr(tiles), ntiles, tile_rows,
-                                 int(transpose and self.valT is not None), _stream()), "sparc_spmm")
+            check(lib.sparc_spmm(self.m, self.nnz, _ptr(self.rowptr), _ptr(self.colidx), _ptr(v), width,
+                                 _ptr(X), _ptr(add), _ptr(Z), ctypes.byref(t) if t is not None else None, _stream()),
+                  "sparc_spmm")
         return Z
 
     def nbytes(self) -> int:

@@ -77,3 +77,25 @@ def block_features(node_ids: np.ndarray, bounds: torch.Tensor, din: int, n_block
     means = np.random.RandomState(seed + 1).standard_normal((n_blocks, din)).astype(np.float32)
     rng = np.random.RandomState(seed + 2 + int(node_ids[0]))
     return torch.from_numpy(means[block] + rng.standard_normal((len(node_ids), din)).astype(np.float32))
+
+
+def shape_batch(workload: str, device, bsize: int | None = None, seed: int = 0):
+    """(ClusterBatch, k) with the statistics of one training batch of a named shape, without generating
+    the whole graph: twice the batch's clusters at their full size and in-cluster edge count, and as
+    many uniform edges as put the full graph's number of cross-cluster entries into the batch (a
+    uniform edge of the full graph has both ends in one batch with probability (m/n)^2, of this graph
+    with probability 1/4)."""
+    from .graph import ClusterBatch
+    shape = SHAPES[workload]
+    bsize = bsize or shape["bsize"]
+    n_clusters = 2 * bsize
+    n = int(shape["n"] * n_clusters / shape["clusters"])
+    e_in = 0.7 * shape["edges"] * n_clusters / shape["clusters"]
+    e_cross = 4 * 0.3 * shape["edges"] * (bsize / shape["clusters"]) ** 2
+    graph, bounds = planted_cluster_graph(n, int(e_in + e_cross), n_clusters, device,
+                                          frac_in_cluster=e_in / (e_in + e_cross), seed=seed)
+    nodes_of, cluster_ids = cluster_batches(bounds, bsize, seed=seed, return_clusters=True)
+    lam = shape["diag_lambda"]
+    coords, values, shp, _ = graph.subblock(nodes_of[0], mode=(0 if lam == -1 else 2), binarize=False, diag_lambda=lam)
+    csz = np.diff(bounds.cpu().numpy())[cluster_ids[0]]
+    return ClusterBatch.from_device_coo(shp[0], coords, values, cluster_sizes=csz), shape["k"]

@@ -30,7 +30,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-def windowed_pattern(rng, sizes, cross_per_row=0.3, hubs=6, hub_out=5, dense_tail=True):
+def windowed_pattern(rng, sizes, cross_per_row=0.3, hubs=6, hub_out=5, dense_tail=True, big_hubs=0):
     """Symmetric 0/1/2-weighted adjacency + identity of a batch of clusters (`sizes` rows each) whose
     in-cluster degrees span one entry to a few hundred, with a few entries between clusters:
     `cross_per_row` expected per row plus `hubs` rows with `hub_out` of them."""
@@ -62,6 +62,13 @@ def windowed_pattern(rng, sizes, cross_per_row=0.3, hubs=6, hub_out=5, dense_tai
     hv = rng.integers(0, m, hubs * hub_out)
     r = np.concatenate([r, cu, hu])
     c_ = np.concatenate([c_, cv, hv])
+    if big_hubs:   # the rows with the most in-cluster entries also get many entries all over the batch
+        deg = np.bincount(r, minlength=m)
+        top = np.argsort(-deg)[:big_hubs]
+        for i, h in enumerate(top):
+            far = rng.choice(m, size=30 + 60 * i, replace=False)
+            r = np.concatenate([r, np.full(len(far), h)])
+            c_ = np.concatenate([c_, far])
     keep = r != c_
     w = np.where(rng.random(keep.sum()) < 0.3, 2.0, 1.0)
     D = sp.coo_matrix((w, (r[keep], c_[keep])), shape=(m, m)).tocsr()
@@ -78,20 +85,23 @@ def make_support(D, flavour):
     return O.as_support_tuple(D)
 
 
-def tiling_census(b, n_slabs):
-    """What the tiling of batch b holds (asserts that there is one)."""
-    tiles, ntiles, tile_rows = b.tiles(n_slabs)
-    assert tiles is not None and ntiles > 0, "the batch has no tiling: the tiled kernel would not run"
-    lo, hi, n_out, _ = b._in_window_ranges()
-    inwin = hi - lo
-    desc = tiles[:ntiles * 8].cpu().numpy().reshape(-1, 8)
+def tiling_census(b, k, training):
+    """What the tiling of batch b for this pass holds (asserts that there is one)."""
+    t = b.tiling(k, training)
+    assert t is not None and t.ndesc > 0, "the batch has no tiling: the windowed kernel would not run"
+    p0, lo, hi, p1 = b._in_window_ranges()
+    inwin, n_out = hi - lo, (lo - p0) + (p1 - hi)
+    desc = t.desc
     return {
         "windows": len(b._windows), "max_w0": max(a for a, _ in b._windows),
         "len_17_32": int(((inwin >= 17) & (inwin <= 32)).sum()), "len_33_64": int(((inwin >= 33) & (inwin <= 64)).sum()),
         "len_65_128": int(((inwin >= 65) & (inwin <= 128)).sum()), "len_gt128": int((inwin > 128).sum()),
-        "out1": int((n_out == 1).sum()), "out2": int((n_out == 2).sum()), "out_gt2": int((n_out > 2).sum()),
-        "loose_wgs": int((desc[:, 4] < 0).sum()), "pad_desc": int(((desc[:, 1] == desc[:, 0]) & (desc[:, 4] >= 0)).sum()),
-        "slabs": int(desc[:, 4].max()) + 1, "ndesc": ntiles, "tile_rows": tile_rows,
+        "out1": int((n_out == 1).sum()), "out2": int((n_out == 2).sum()), "out_5_16": int(((n_out > 4) & (n_out <= 16)).sum()),
+        "out_gt16": int((n_out > 16).sum()), "long_with_out": int(((inwin > 64) & (n_out > 0)).sum()),
+        "long_out_gt64": int(((inwin > 64) & (n_out > 64)).sum()),
+        "before": int(((lo - p0) > 0).sum()), "after": int(((p1 - hi) > 0).sum()),
+        "pad_desc": int((desc[:, 1] == desc[:, 0]).sum()),
+        "slabs": int(desc[:, 4].max()) + 1, "ndesc": t.ndesc, "tile_rows": t.rows, "vec": t.vec, "kp": t.kp,
     }
 
 
@@ -101,7 +111,7 @@ SIZES = [400, 110, 380, 300, 200, 450, 60, 512, 333, 1, 96, 280]   # 12 clusters
 @pytest.fixture(scope="module")
 def big_fixture():
     rng = np.random.default_rng(2024)
-    D = windowed_pattern(rng, SIZES)
+    D = windowed_pattern(rng, SIZES, big_hubs=3)
     out = {}
     for flavour in ("enh", "raw"):
         s = make_support(D, flavour)
@@ -111,19 +121,23 @@ def big_fixture():
 
 
 @pytest.mark.parametrize("flavour", ["enh", "raw"])
-@pytest.mark.parametrize("k", [20, 32, 47, 48, 64])
-def test_tiled_lap_matches_oracle_all_row_classes(dev, big_fixture, flavour, k):
+@pytest.mark.parametrize("k", [7, 20, 32, 47, 48, 64])
+@pytest.mark.parametrize("vec", [2, 4])
+def test_tiled_lap_matches_oracle_all_row_classes(dev, big_fixture, flavour, k, vec, monkeypatch):
     from sparc_amd.graph import ClusterBatch
     s, A, _, prep = big_fixture[flavour]
     m = A.shape[0]
     rng = np.random.default_rng(k)
     Y = rng.standard_normal((m, k)).astype(np.float32)
     loss_o, g_o, _, _ = O.lap_forward_operator(A, prep, Y.astype(np.float64))
+    monkeypatch.setattr(ClusterBatch, "tile_vec", vec)
     b = ClusterBatch.from_support(s, dev, cluster_sizes=SIZES)
     assert (b.valT is None) == (flavour == "raw")
-    cen = tiling_census(b, b.train_slabs(k))
+    cen = tiling_census(b, k, True)
+    assert cen["vec"] == vec and cen["kp"] >= k and cen["kp"] - k < 8 * vec
     assert cen["windows"] >= 5 and cen["max_w0"] > 0
-    for key in ("len_17_32", "len_33_64", "len_65_128", "len_gt128", "out1", "out2", "out_gt2", "loose_wgs", "pad_desc"):
+    for key in ("len_17_32", "len_33_64", "len_65_128", "len_gt128", "out1", "out2", "out_5_16", "out_gt16",
+                "long_with_out", "long_out_gt64", "before", "after", "pad_desc"):
         assert cen[key] > 0, (key, cen)
     Yd = torch.tensor(Y, device=dev)
     loss, grad = b.lap(Yd, True)
@@ -133,28 +147,25 @@ def test_tiled_lap_matches_oracle_all_row_classes(dev, big_fixture, flavour, k):
     gn = np.abs(g_o).max(axis=1)
     err_rows = np.abs(grad.cpu().numpy() - g_o).max(axis=1) / np.maximum(gn, 1e-3 * gn.max())
     assert err_rows.max() < 5e-4, int(err_rows.argmax())
-    if k == 64:   # forward-only (validation) variant of the tiled kernel
-        tiling_census(b, 1)
+    if k > 16:   # forward-only (validation) variant of the windowed kernel
+        tiling_census(b, k, False)
         lv, none = b.lap(Yd, False)
         assert none is None and rel(lv.item(), loss_o) < TOL
     # the plain row kernel on the same batch: both are oracle-checked, and agree closely
-    try:
-        ClusterBatch.use_tiles = False
-        loss_r, grad_r = b.lap(Yd, True)
-    finally:
-        ClusterBatch.use_tiles = True
+    monkeypatch.setattr(ClusterBatch, "use_tiles", False)
+    assert b.tiling(k, True) is None
+    loss_r, grad_r = b.lap(Yd, True)
     assert rel(loss_r.item(), loss.item()) < 1e-5 and rel(grad_r.cpu().numpy(), grad.cpu().numpy()) < 1e-5
 
 
 @pytest.mark.parametrize("flavour", ["enh", "raw"])
-def test_tiled_spmm_matches_scipy(dev, big_fixture, flavour):
+@pytest.mark.parametrize("width", [32, 64])
+def test_tiled_spmm_matches_scipy(dev, big_fixture, flavour, width):
     from sparc_amd.graph import ClusterBatch
     s, A, At, _ = big_fixture[flavour]
     m = A.shape[0]
     b = ClusterBatch.from_support(s, dev, cluster_sizes=SIZES)
-    cen = tiling_census(b, 1)
-    assert cen["len_gt128"] > 0 and cen["out2"] > 0 and cen["loose_wgs"] > 0
-    X = np.random.default_rng(1).standard_normal((m, 64)).astype(np.float32)
+    X = np.random.default_rng(1).standard_normal((m, width)).astype(np.float32)
     Xd = torch.tensor(X, device=dev)
     assert rel(b.spmm(Xd, tiled=True).cpu().numpy(), A @ X.astype(np.float64)) < 1e-5
     assert rel(b.spmm(Xd, add=Xd, transpose=True, tiled=True).cpu().numpy(), X + At @ X.astype(np.float64)) < 1e-5
@@ -183,8 +194,9 @@ def test_tiled_windows_that_cut_clusters(dev, hint):
     b = ClusterBatch.from_support(s, dev, cluster_sizes=cs)
     loss, grad = b.lap(torch.tensor(Y, device=dev), True)
     assert rel(loss.item(), loss_o) < TOL and rel(grad.cpu().numpy(), g_o) < TOL
-    if hint != "halves":   # "halves" cuts every cluster: no tiling, the row kernel runs
-        tiling_census(b, b.train_slabs(k))
+    cen = tiling_census(b, k, True)   # tiled under every hint; "halves" leaves many entries outside the windows
+    if hint == "halves":
+        assert cen["out_5_16"] > 100
 
 
 def test_untileable_batch_falls_back_to_row_kernel(dev):
@@ -198,7 +210,7 @@ def test_untileable_batch_falls_back_to_row_kernel(dev):
     D = sp.csr_matrix(sp.triu(R, 1) + sp.triu(R, 1).T + sp.eye(m))
     s = make_support(D, "enh")
     b = ClusterBatch.from_support(s, dev, cluster_sizes=[500, 400, 600])
-    assert b.tiles(b.train_slabs(k))[0] is None
+    assert b.tiling(k, True) is None and b.tiling(k, False) is None
     A, _ = O.csr_from_support(s)
     Y = rng.standard_normal((m, k)).astype(np.float32)
     loss_o, g_o, _, _ = O.lap_forward_operator(A, O.affinity_prep_operator(A), Y.astype(np.float64))
@@ -206,45 +218,22 @@ def test_untileable_batch_falls_back_to_row_kernel(dev):
     assert rel(loss.item(), loss_o) < TOL and rel(grad.cpu().numpy(), g_o) < TOL
 
 
-def _shape_batch(dev, workload):
-    """One training batch with the statistics of a BASELINE shape without generating the whole graph: twice
-    the batch's clusters at their full size and in-cluster edge count, and as many uniform edges as put the
-    full graph's number of cross-cluster entries into the batch (a uniform edge of the full graph has both
-    ends in one batch with probability (m/n)^2, of this graph with probability 1/4)."""
-    from sparc_amd import synth
-    from sparc_amd.graph import ClusterBatch
-    shape = synth.SHAPES[workload]
-    n_clusters = 2 * shape["bsize"]
-    n = int(shape["n"] * n_clusters / shape["clusters"])
-    e_in = 0.7 * shape["edges"] * n_clusters / shape["clusters"]
-    e_cross = 4 * 0.3 * shape["edges"] * (shape["bsize"] / shape["clusters"]) ** 2
-    graph, bounds = synth.planted_cluster_graph(n, int(e_in + e_cross), n_clusters, dev,
-                                                frac_in_cluster=e_in / (e_in + e_cross), seed=0)
-    nodes_of, cluster_ids = synth.cluster_batches(bounds, shape["bsize"], seed=0, return_clusters=True)
-    lam = shape["diag_lambda"]
-    coords, values, shp, _ = graph.subblock(nodes_of[0], mode=(0 if lam == -1 else 2), binarize=False, diag_lambda=lam)
-    csz = np.diff(bounds.cpu().numpy())[cluster_ids[0]]
-    return ClusterBatch.from_device_coo(shp[0], coords, values, cluster_sizes=csz), shape["k"]
-
-
-@pytest.mark.parametrize("workload,min_m,min_nnz", [("amazon2m", 24000, 600_000)])
-def test_full_size_batch_tiled_equals_row_kernel(dev, workload, min_m, min_nnz):
+@pytest.mark.parametrize("workload,min_m,min_nnz", [("amazon2m", 24000, 600_000), ("reddit", 7500, 700_000)])
+def test_full_size_batch_tiled_equals_row_kernel(dev, workload, min_m, min_nnz, monkeypatch):
     """The benched batch shapes: the tiled kernel against the (oracle-checked) row kernel, plus the
     size-independent properties of the loss."""
     from sparc_amd.graph import ClusterBatch
-    b, k = _shape_batch(dev, workload)
+    from sparc_amd import synth
+    b, k = synth.shape_batch(workload, dev)
     assert b.m >= min_m and b.nnz >= min_nnz, (b.m, b.nnz)
-    cen = tiling_census(b, b.train_slabs(k))
-    assert cen["windows"] >= 16 and cen["len_33_64"] > 0, cen
+    cen = tiling_census(b, k, True)
+    assert cen["windows"] >= 16 and cen["len_33_64"] + cen["len_65_128"] + cen["len_gt128"] > 0, cen
     gen = torch.Generator(device=dev).manual_seed(1)
     Y = torch.randn(b.m, k, device=dev, generator=gen)
     loss, grad = b.lap(Y, True)
     lv, _ = b.lap(Y, False)
-    try:
-        ClusterBatch.use_tiles = False
-        loss_r, grad_r = b.lap(Y, True)
-    finally:
-        ClusterBatch.use_tiles = True
+    monkeypatch.setattr(ClusterBatch, "use_tiles", False)
+    loss_r, grad_r = b.lap(Y, True)
     assert rel(loss.item(), loss_r.item()) < 1e-5
     assert rel(grad.cpu().numpy(), grad_r.cpu().numpy()) < 1e-5
     assert rel(lv.item(), loss_r.item()) < 1e-5

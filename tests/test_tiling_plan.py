@@ -1,10 +1,10 @@
-"""Host side of the LDS-tiled kernel: windows and the tiling buffer (layout in include/sparc_hip.h).
+"""Host side of the windowed (LDS-tiled) kernel: windows and the tiling buffer (layout in include/sparc_hip.h).
 The kernel trusts these invariants (every (row, slab) produced exactly once, windows within the LDS
 budget, records sorted by length inside a workgroup), so they are pinned here without a GPU."""
 import numpy as np
 import pytest
 
-from sparc_amd.graph import TILE_LONG_ROW, TILE_MAX_OUTSIDE, TILE_MAX_ROWS, plan_tiles, plan_windows
+from sparc_amd.graph import TILE_LONG_ROW, TILE_MAX_ROWS, plan_tiles, plan_windows
 
 
 @pytest.mark.parametrize("sizes", [[130, 40, 333, 700, 1, 96], [490] * 50, [5], [2000], [0, 7, 0, 9]])
@@ -24,30 +24,28 @@ def test_windows_without_hint_are_equal_cuts():
     assert plan_windows(1300, [5, 5]) == wins     # a hint that does not add up is ignored
 
 
-def _random_rows(m, wins, rng, p_out=0.1, max_len=150):
-    lo = np.zeros(m, np.int64)
-    hi = np.zeros(m, np.int64)
-    n_out = np.zeros(m, np.int64)
+def _random_rows(m, rng, p_out=0.1, max_len=150):
+    """Per row: stored entries [p0, p1), of which [lo, hi) inside the window."""
+    p0 = np.zeros(m, np.int64); lo = np.zeros(m, np.int64); hi = np.zeros(m, np.int64); p1 = np.zeros(m, np.int64)
     pos = 0
     for r in range(m):
+        before = int(rng.integers(0, 4)) if rng.random() < p_out else 0
+        after = int(rng.integers(0, 40)) if rng.random() < p_out else 0
         ln = int(rng.integers(0, max_len)) if rng.random() < 0.1 else int(rng.integers(0, 30))
-        lo[r], hi[r] = pos, pos + ln
-        pos += ln
-        n_out[r] = rng.integers(1, 6) if rng.random() < p_out else 0
-        pos += int(n_out[r])
-    out_rec = rng.integers(0, 1000, size=(m, 6)).astype(np.int64)
-    return lo, hi, n_out, out_rec
+        p0[r], lo[r], hi[r], p1[r] = pos, pos + before, pos + before + ln, pos + before + ln + after
+        pos = p1[r]
+    return p0, lo, hi, p1
 
 
-@pytest.mark.parametrize("n_slabs", [1, 2])
-def test_tiling_buffer_invariants(n_slabs):
+@pytest.mark.parametrize("n_slabs,threads", [(1, 1024), (2, 512), (3, 512), (4, 256)])
+def test_tiling_buffer_invariants(n_slabs, threads):
     rng = np.random.default_rng(3)
     sizes = [300, 512, 45, 700, 130]
     m = sum(sizes)
     wins = plan_windows(m, sizes)
-    lo, hi, n_out, out_rec = _random_rows(m, wins, rng)
-    desc, recs = plan_tiles(wins, lo, hi, n_out, out_rec, n_slabs)
-    assert desc.dtype == np.int32 and recs.dtype == np.int32 and desc.shape[1] == 8 and recs.shape == (m, 12)
+    p0, lo, hi, p1 = _random_rows(m, rng)
+    desc, recs = plan_tiles(wins, p0, lo, hi, p1, n_slabs, threads)
+    assert desc.dtype == np.int32 and recs.dtype == np.int32 and desc.shape[1] == 8 and recs.shape == (m, 4)
     assert sorted(recs[:, 0].tolist()) == list(range(m))                      # every row has exactly one record
     produced = np.zeros((m, n_slabs), np.int64)
     xcd_of_window = {}
@@ -56,21 +54,15 @@ def test_tiling_buffer_invariants(n_slabs):
             assert (w0, w1, slab, n_long) == (0, 0, 0, 0)
             continue
         rows = recs[q0:q1, 0]
-        if slab >= 0:                                                         # all workgroups of a window on one XCD
-            assert xcd_of_window.setdefault((w0, w1), pos % 8) == pos % 8
-        if slab < 0:                                                          # rows gathered whole from global memory
-            assert np.all(n_out[rows] > TILE_MAX_OUTSIDE)
-            produced[rows, :] += 1
-            continue
+        assert xcd_of_window.setdefault((w0, w1), pos % 8) == pos % 8         # all workgroups of a window on one XCD
         assert 0 <= slab < n_slabs and 0 < w1 - w0 <= TILE_MAX_ROWS
         assert np.all((rows >= w0) & (rows < w1))                             # a workgroup's rows lie in its window
-        assert np.all(n_out[rows] <= TILE_MAX_OUTSIDE)
-        length = recs[q0:q1, 2] - recs[q0:q1, 1]
+        length = recs[q0:q1, 2]
         assert np.all(np.diff(length) <= 0)                                   # longest first
         assert n_long == int((length > TILE_LONG_ROW).sum())
-        assert np.array_equal(recs[q0:q1, 1], lo[rows]) and np.array_equal(recs[q0:q1, 2], hi[rows])
-        assert np.array_equal(recs[q0:q1, 3], np.minimum(n_out[rows], TILE_MAX_OUTSIDE))
-        assert np.array_equal(recs[q0:q1, 4:10], out_rec[rows])
+        assert np.array_equal(recs[q0:q1, 1], p0[rows]) and np.array_equal(length, (hi - lo)[rows])
+        assert np.array_equal(recs[q0:q1, 3] >> 16, (lo - p0)[rows])          # entries before the window
+        assert np.array_equal(recs[q0:q1, 3] & 0xFFFF, (p1 - hi)[rows])       # ... and behind it
         produced[rows, slab] += 1
     assert np.all(produced == 1)                                              # every (row, slab) exactly once
 
@@ -78,8 +70,8 @@ def test_tiling_buffer_invariants(n_slabs):
 def test_tiling_fills_the_chip_when_windows_are_few():
     wins = plan_windows(980, [490, 490])
     rng = np.random.default_rng(0)
-    lo, hi, n_out, out_rec = _random_rows(980, wins, rng, p_out=0.0)
-    desc, _ = plan_tiles(wins, lo, hi, n_out, out_rec, 2)
+    p0, lo, hi, p1 = _random_rows(980, rng, p_out=0.0)
+    desc, _ = plan_tiles(wins, p0, lo, hi, p1, 2, 512)
     per_window = {}
     for q0, q1, w0, w1, slab, *_ in desc:
         if q1 > q0:

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Kernel-level timing of the Laplacian chain passes on one Amazon2M-shape cluster batch.
-Run under rocprofv3 --kernel-trace --stats to read per-kernel durations; SPARC_DBG selects
-ablations of the tiled kernel (1: no row loop, 2: no gather steps, 4: no staging)."""
+"""Kernel-level timing of the Laplacian chain passes on one cluster batch of a named shape
+(WORKLOAD=amazon2m|reddit|pubmed, BSIZE clusters per batch, K spectral dimension).  Run under
+rocprofv3 --kernel-trace --stats to read per-kernel durations.  VEC / THREADS / WGS select the
+windowed kernel's geometry (floats per lane, workgroup size, workgroups to aim for)."""
 import os
 import sys
 import time
 
-import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,27 +14,30 @@ from sparc_amd import synth
 from sparc_amd.graph import ClusterBatch
 
 dev = torch.device("cuda:0")
-scale = float(os.environ.get("SCALE", "1.0"))
-n = int(2449029 * scale)
-graph, bounds = synth.planted_cluster_graph(n, int(61859140 * scale), int(5000 * scale), dev, seed=0)
-nodes_of, cids = synth.cluster_batches(bounds, int(os.environ.get("BSIZE", "50")), seed=0, return_clusters=True)
-pt = nodes_of[0]
-coords, values, shp, _ = graph.subblock(pt, mode=2, binarize=False, diag_lambda=0.01)
-csz = np.diff(bounds.cpu().numpy())[cids[0]]
-b = ClusterBatch.from_device_coo(shp[0], coords, values, cluster_sizes=csz)
-k = int(os.environ.get("K", "47"))
-lo, hi, n_out, _ = b._in_window_ranges()
-print(f"rows with entries outside their window: {int((n_out > 0).sum())} (more than two: {int((n_out > 2).sum())}) of {b.m}; windows {len(b._windows)}; descriptors {b.tiles(2)[1]} tiled={b.tiles(2)[0] is not None}", flush=True)
+workload = os.environ.get("WORKLOAD", "amazon2m")
+bsize = int(os.environ.get("BSIZE", "0")) or None
+b, k = synth.shape_batch(workload, dev, bsize=bsize)
+k = int(os.environ.get("K", k))
+ClusterBatch.tile_vec = int(os.environ.get("VEC", "2"))
+ClusterBatch.tile_threads = int(os.environ.get("THREADS", "0")) or None
+ClusterBatch.tile_target_wgs = int(os.environ.get("WGS", "0")) or None
+p0, lo, hi, p1 = b._in_window_ranges()
+n_out = (lo - p0) + (p1 - hi)
+t = b.tiling(k, True)
+print(f"{workload}: m={b.m} nnz={b.nnz} k={k} windows={len(b._windows)} entries outside their window: "
+      f"{int(n_out.sum())} ({n_out.sum() / b.nnz:.3f}); tiling: "
+      + (f"vec={t.vec} kp={t.kp} threads={t.threads} descriptors={t.ndesc} rows={t.rows}" if t else "none"), flush=True)
 Y = torch.randn(b.m, k, device=dev)
 reps = int(os.environ.get("REPS", "20"))
 for tiles in (True, False):
     ClusterBatch.use_tiles = tiles
     for _ in range(3):
         b.lap(Y, True)
+        b.lap(Y, False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
         b.lap(Y, True)
     torch.cuda.synchronize()
-    alg = b.nnz * 12 + (b.m + 1) * 8 + 3 * b.m * 128 * 4
-    print(f"tiles={tiles} m={b.m} nnz={b.nnz} algorithmic bytes per inner pass {alg} lap_fwd(dual) {1e6 * (time.perf_counter() - t0) / reps:.1f} us/call", flush=True)
+    alg = b.nnz * (12 if b.valT is not None else 8) + (b.m + 1) * 8 + 3 * b.m * 2 * k * 4
+    print(f"tiles={tiles} algorithmic bytes per inner pass {alg} lap_fwd(dual) {1e6 * (time.perf_counter() - t0) / reps:.1f} us/call", flush=True)
