@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+F64_MFMA_PEAK_TFLOPS = 78.6  # MI355X dense FP64 matrix peak (vendor data sheet)
 
 
 def log(*a):
@@ -32,7 +33,7 @@ def log(*a):
         print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(graph, batches_nodes, bounds, shape, arch, sample_nodes, threads):
+def cpu_baseline(graph, batches_nodes, bounds, shape, arch, sample_nodes, threads, full_nodes=0):
     """The dense torch restatement of the reference step (the oracle) on the host CPU,
     on a bounded sample: the first `sample_nodes` nodes of two training batches."""
     from oracle import sparc_oracle as O
@@ -59,10 +60,80 @@ def cpu_baseline(graph, batches_nodes, bounds, shape, arch, sample_nodes, thread
         params = O.adam_update(params, out["grads"], state)
         times.append(time.perf_counter() - t0)
     t = float(np.median(times[1:]))
-    return {"value": len(pt1) / t, "unit": "nodes/s", "cores": threads, "kind": "port",
-            "sample": f"dense reference-step restatement (oracle), float32, one step on the first {len(pt1)} nodes of a "
-                      f"training batch (+{len(pt2)}-node orthonormalisation batch), median of 2 after 1 warm-up, "
-                      f"{t:.2f} s/step"}
+    out = {"value": len(pt1) / t, "unit": "nodes/s", "cores": threads, "kind": "port",
+           "sample": f"dense reference-step restatement (oracle), float32, one step on the first {len(pt1)} nodes of a "
+                     f"training batch (+{len(pt2)}-node orthonormalisation batch), median of 2 after 1 warm-up, "
+                     f"{t:.2f} s/step"}
+    if full_nodes > len(pt1):
+        # the dense step is dominated by three m x m x m products: time grows with the cube of the batch size
+        t_full = t * (full_nodes / len(pt1)) ** 3
+        out["full_batch_extrapolation"] = {"nodes": full_nodes, "seconds_per_step": t_full, "nodes_per_s": full_nodes / t_full,
+                                           "rule": "sample time x (m / sample)^3: the dense affinity costs 3 m^3 multiply-adds"}
+    return out
+
+
+def inner_pass_bytes(b, k):
+    """(algorithmic, moved) bytes of ONE inner pass of the Laplacian chain on batch b at spectral dimension k:
+    the entry streams once, the row pointers, and three dense operands of width 2k (gathered operand,
+    own-row operand, result) -- at the real k for the algorithmic figure, at the kernel's column padding for
+    the bytes it actually moves."""
+    entry = b.nnz * (4 + 4 + (4 if b.valT is not None else 0)) + (b.m + 1) * 8
+    t = b.tiling(k, True)
+    kp = t.kp if t is not None else (16 if k <= 16 else 32 if k <= 32 else 64)
+    return entry + 3 * b.m * 2 * k * 4, entry + 3 * b.m * 2 * kp * 4
+
+
+def recorded_traffic(workload, b, k):
+    """HBM bytes per launch of the inner pass from the rocprofv3 counter passes (tools/run_pmc.sh,
+    tools/collect_traffic.py) -- only if they were taken on this workload's batch shape; else None."""
+    path = os.path.join(ROOT, "profiles", "spmm_hbm_traffic.json")
+    try:
+        rec = json.load(open(path))
+    except Exception:
+        return None
+    same = rec.get("workload") == workload and rec.get("k") == k and abs(rec.get("m", 0) - b.m) <= 0.05 * b.m and \
+        abs(rec.get("nnz", 0) - b.nnz) <= 0.05 * b.nnz
+    return rec.get("bytes_per_launch") if same else None
+
+
+def side_measurements(trainer, lib, check, k, dev, reps=30):
+    """Outside the timed region: average duration of the last pass of the chain (loss + gradient epilogue)
+    and of the Gram product of the orthonormalisation, each on batch 0, with events on the launch stream."""
+    import ctypes
+    from sparc_amd.ops import gram
+    b = trainer.batches[0]
+    Y = torch.randn(b.m, k, device=dev)
+    for _ in range(3):
+        b.lap(Y, True)
+    torch.cuda.synchronize()
+    check(lib.sparc_profile_begin(4, reps), "sparc_profile_begin")
+    for _ in range(reps):
+        b.lap(Y, True)
+    torch.cuda.synchronize()
+    tot, n = ctypes.c_double(0.0), ctypes.c_int64(0)
+    check(lib.sparc_profile_end(ctypes.byref(tot), ctypes.byref(n)), "sparc_profile_end")
+    lap_us = tot.value / max(n.value, 1) * 1e3
+    alg, _ = inner_pass_bytes(b, k)
+    lap_alg = alg - b.m * 2 * k * 4 + b.m * k * 4 + b.m * 32     # writes the gradient [m][k] instead of [m][2k]; reads the row records
+    for _ in range(3):
+        gram(Y, Y)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(reps):
+        gram(Y, Y)
+    ev[1].record()
+    torch.cuda.synchronize()
+    gram_us = ev[0].elapsed_time(ev[1]) / reps * 1e3
+    flops = 2.0 * b.m * k * k
+    return {
+        "lap_last_pass": {"avg_kernel_us": lap_us, "algorithmic_bytes": lap_alg,
+                          "achieved_GBs": lap_alg / (lap_us * 1e-6) / 1e9, "frac_of_hbm_peak": lap_alg / (lap_us * 1e-6) / 1e9 / HBM_PEAK_GBS},
+        "gram": {"avg_us_two_launches": gram_us, "flop": flops, "achieved_TFLOPs_f64": flops / (gram_us * 1e-6) / 1e12,
+                 "f64_mfma_peak_TFLOPs": F64_MFMA_PEAK_TFLOPS, "mfma_utilisation": flops / (gram_us * 1e-6) / 1e12 / F64_MFMA_PEAK_TFLOPS,
+                 "achieved_GBs": 2.0 * b.m * k * 4 / (gram_us * 1e-6) / 1e9,
+                 "note": "gram_partial + gram_reduce back to back; the product reads 2*m*k*4 bytes for 2*m*k^2 flop, i.e. it is "
+                         "HBM/launch bound long before the matrix cores matter"},
+    }
 
 
 def main():
@@ -150,14 +221,15 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     nodes = 0
-    alg_bytes = 0.0
+    alg_bytes = moved_bytes = 0.0
     losses = []
     for s in range(args.warmup, args.warmup + args.steps):
         pid, loss = one_step(s)
         nodes += ms[pid]
         b = trainer.batches[pid]
-        width = 2 * (16 if k <= 16 else 32 if k <= 32 else 64)
-        alg_bytes += 2 * (b.nnz * (4 + 4 + (4 if b.valT is not None else 0)) + (b.m + 1) * 8 + 3 * b.m * width * 4)
+        a_b, m_b = inner_pass_bytes(b, k)
+        alg_bytes += 2 * a_b
+        moved_bytes += 2 * m_b
         losses.append(loss)
     torch.cuda.synchronize()
     if world > 1:
@@ -182,13 +254,10 @@ def main():
         kern_ms = tot_ms.value / max(launches.value, 1)
         per_launch = alg_bytes / max(2 * args.steps, 1)
         achieved = per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "spmm_hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("bytes_per_launch")
-            except Exception:
-                traffic = None
+        b0 = trainer.batches[0]
+        t0_ = b0.tiling(k, True)
+        kernel = (f"spmm_win<vec {t0_.vec}, dual, add-x0> (kp {t0_.kp})" if t0_ is not None else "spmm_rows<dual, add-x0> (kp 64)") + \
+            ": the two inner passes of the Laplacian chain"
         out = {
             "metric": "SpectralNet train nodes/sec + SpMM HBM GB/s (% roofline), Amazon2M shape",
             "value": nodes / elapsed, "unit": "nodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -201,15 +270,21 @@ def main():
                        "batches_per_gpu": nb, "prep_seconds_per_batch": t_prep / max(nb, 1),
                        "parallelism": f"dp{world} (cluster batches sharded, flat-gradient all-reduce)",
                        "mean_loss": final_loss},
-            "roofline": {"bound": "hbm", "kernel": "spmm_tiled<dual, add-x0> (inner passes of the Laplacian chain; "
-                                                   "spmm_rows when a batch has no tiling)",
+            "roofline": {"bound": "hbm", "kernel": kernel,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "avg_kernel_us": kern_ms * 1e3, "launches_timed": int(launches.value),
-                         "algorithmic_bytes_per_launch": per_launch},
+                         "traffic": recorded_traffic(args.workload, b0, k), "avg_kernel_us": kern_ms * 1e3,
+                         "launches_timed": int(launches.value),
+                         "algorithmic_bytes_per_launch": per_launch,
+                         "algorithmic_bytes_formula": "nnz*(4+4[+4 mirrored values]) + 8*(m+1) + 3*m*(2k)*4 (gathered operand, "
+                                                      "own-row operand, result; width 2k = [A half | A^T half])",
+                         "bytes_moved_per_launch": moved_bytes / max(2 * args.steps, 1)},
         }
+        if world == 1:
+            out["other_kernels"] = side_measurements(trainer, lib, check, k, dev)
         if world == 1 and not args.no_cpu_baseline:
             threads = min(16, os.cpu_count() or 1)
-            out["cpu_baseline"] = cpu_baseline(graph, nodes_of, bounds, shape, arch, args.cpu_sample, threads)
+            out["cpu_baseline"] = cpu_baseline(graph, nodes_of, bounds, shape, arch, args.cpu_sample, threads,
+                                               full_nodes=int(np.mean(ms)))
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

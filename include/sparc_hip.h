@@ -88,24 +88,36 @@ int sparc_affinity_prep(int64_t m, int64_t nnz, const int64_t* rowptr, const int
  * loss is one device double. */
 size_t sparc_lap_workspace_bytes(int64_t m, int k, int ntiles);
 
-/* Cluster tiling (optional; NULL selects the plain row kernel).  A HOST struct that describes one
- * device buffer of int32 in two parts:
- *   ndesc descriptors  {q_begin, q_end, win_begin, win_end, slab, n_long, 0, 0}
- *   m row records      {row, p0, n_in, n_before << 16 | n_after}
+/* Cluster tiling (optional; NULL selects the plain row kernel).  A HOST struct that describes a work
+ * plan and a copy of the batch's stored entries in the order the windowed kernel consumes them.
+ *
  * The dense operand of a tiled pass is kept slab-major: slab s is a row-major [m][16 vec] matrix
  * holding columns [s hw, (s+1) hw) of the A half and, in the training pass, the same columns of
  * the A^T half behind them (hw = 8 vec columns per half; forward-only pass: hw = 16 vec columns).
- * A workgroup stages rows [win_begin, win_end) of slab `slab` in LDS and produces the rows of records
- * [q_begin, q_end), all inside its window.  A row's stored entries are [p0, p0 + n_before) with
- * columns before the window, then n_in entries inside it (gathered from LDS), then n_after behind it
- * (both outside runs are gathered from global memory; each at most 65535 long).  Records of one
- * workgroup are sorted by n_in, longest first: the first n_long of them (rows with more than
- * SPARC_TILE_LONG_ROW in-window entries) get a whole wavefront each, the others share a wavefront
- * four at a time and the first of the four bounds its trip count: it MUST be the longest of the
- * four.  Every (row, slab) pair must be produced exactly once; a descriptor with q_begin == q_end is
- * an empty workgroup (padding that lets a caller place the workgroups of one window on one XCD:
- * workgroup b runs on XCD b % 8).  kp (a multiple of hw, >= k) is the padded number of columns per
- * half; rows = the largest window, rows * 64 * vec <= 128 KiB; nnz < 2^31. */
+ *
+ * buf (device int32) = ndesc descriptors {slot_begin, slot_end, win_begin, win_end, slab, n_long, has_outside, 0}
+ * followed by the slot records, four per slot: {row, s_pos, o_pos, L | O << 16}.
+ * A workgroup stages rows [win_begin, win_end) of slab `slab` in LDS and works through the slots
+ * [slot_begin, slot_end) (at most SPARC_TILE_MAX_RECORDS / 4), one wavefront per slot; has_outside
+ * must be 1 if any of these slots has O > 0 (0 lets the workgroup skip the outside path).  A slot holds four
+ * rows of the window, one per 16-lane group of the wavefront (record g = row of group g, -1: none), or,
+ * for the first n_long slots of a workgroup, ONE row (record 0) that all four groups share (the planner
+ * of this package gives rows with more than SPARC_TILE_LONG_ROW in-window entries a slot of their own).  Entries
+ * whose column lies inside the window are gathered from LDS, the others from global memory:
+ *   s_addr / s_val / s_valT [s_pos + 16 j + 4 g + q], j < L, q < 4: entry 4 j + q of row g (four-row
+ *       slot) or entry 16 j + 4 g + q of the row (one-row slot); s_addr = (column - win_begin) * 64 vec,
+ *       the byte offset of the operand row inside the LDS window;
+ *   o_row / o_val / o_valT [o_pos + 4 j + g], j < O: outside entry j of row g, or outside entry 4 j + g
+ *       of the row; o_row = column.
+ * Both streams are padded with zero-valued entries up to the slot's L and O (the same for its four
+ * records; the kernel reads them from record 0's group); s_pos is a multiple of 4, and the streams
+ * must be readable 16 entries past the last slot.  s_valT / o_valT are used by the training pass
+ * only (the mirrored values A[j, i]; they may alias s_val / o_val for a symmetric matrix).  Slots of
+ * a workgroup are ordered by decreasing work; every (row, slab) pair must be produced exactly once;
+ * a descriptor with slot_begin == slot_end is an empty workgroup (padding that lets a caller place
+ * the workgroups of one window on one XCD: workgroup b runs on XCD b % 8).  kp (a multiple of hw,
+ * >= k) is the padded number of columns per half; rows = the largest window, rows * 64 * vec <=
+ * 128 KiB. */
 typedef struct sparc_tiling {
     const int32_t* buf; /* device */
     int32_t ndesc;
@@ -114,8 +126,15 @@ typedef struct sparc_tiling {
     int32_t threads; /* workgroup size: a multiple of 64, at most 1024 */
     int32_t kp;
     int32_t dual;    /* 1: planned for the training pass (loss + gradient), 0: forward only */
+    const int32_t* s_addr; /* device: the entry streams */
+    const float* s_val;
+    const float* s_valT;
+    const int32_t* o_row;
+    const float* o_val;
+    const float* o_valT;
 } sparc_tiling_t;
-#define SPARC_TILE_LONG_ROW 64
+#define SPARC_TILE_LONG_ROW 128
+#define SPARC_TILE_MAX_RECORDS 512
 
 int sparc_lap_fwd(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* colidx,
                   const float* val, const float* valT, const float* rowc, const double* coupling,
@@ -126,7 +145,8 @@ int sparc_lap_fwd(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* 
 /* Plain product Z = A X (+ X0 if X0 != NULL) on the same kernels, X, X0, Z [m][width] with
  * width in {16, 32, 64, 128}; pass the mirrored values as `val` for A^T X.  With a tiling
  * (dual = 0, kp = width = 16 vec: one slab, which is the row-major operand itself) the windowed
- * kernel runs.  Exposed for roofline measurements on whole graphs. */
+ * kernel runs and takes the values from the tiling's streams (built from the mirrored values
+ * for A^T X).  Exposed for roofline measurements on whole graphs. */
 int sparc_spmm(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* colidx,
                const float* val, int width, const float* X, const float* X0, float* Z,
                const sparc_tiling_t* tiling, sparc_stream_t stream);

@@ -14,6 +14,7 @@ enum SpmmEpilogue {
 
 struct SpmmArgs {
     int64_t m;
+    int64_t nnz;
     const int64_t* rowptr;
     const int32_t* col;
     const float* val;
@@ -29,15 +30,24 @@ struct SpmmArgs {
     int64_t ldy;
     int k;
     float inv_m;
-    // windowed kernel: work descriptors int32[ndesc][8] and row records int32[m][4] (layout: include/sparc_hip.h)
+    // windowed kernel: work descriptors int32[ndesc][8], slot records int32[.][4] and the entry streams
+    // (layout: include/sparc_hip.h)
     const int32_t* desc;
     const int32_t* rowinfo;
+    const int32_t* s_addr;
+    const float* s_val;
+    const float* s_valT;
+    const int32_t* o_row;
+    const float* o_val;
+    const float* o_valT;
     int ndesc;
     int tile_rows;   // largest window (rows) over all descriptors
     int vec;         // floats per lane: a slab row is 16 * vec floats
     int threads;     // workgroup size
     int64_t plane;   // floats between two slabs of the slab-major operand (m * 16 * vec)
     int kp;          // columns per half (dual) or per row (single): the stride of M12
+    long long* stamps;  // developer timeline buffer or null
+    int dbg;         // ablation switches for kernel timing experiments (0 in production)
     // affinity preparation epilogue
     double* racc;  // [m][8] {sum sq, S 1, S c, S c2 (all off-diagonal), S_ii}
     const double* cvec;

@@ -28,6 +28,7 @@ namespace {
 
 constexpr int ROWS_PER_BLOCK = 4;  // spmm_rows: one row per wave
 constexpr int WIN_MAX_THREADS = 1024;  // spmm_win: workgroup size is a launch parameter, up to 16 waves
+constexpr int WIN_MAX_RECORDS = SPARC_TILE_MAX_RECORDS;  // rows of one workgroup (their records sit in LDS)
 
 // ------------------------------------------------------------------ shared epilogue
 // A lane owns VEC consecutive columns of one row: `cl` is their index inside the half (0..kp-1),
@@ -278,22 +279,50 @@ template <int VEC> struct VecOf;
 template <> struct VecOf<2> { typedef float T __attribute__((ext_vector_type(2))); };
 template <> struct VecOf<4> { typedef float T __attribute__((ext_vector_type(4))); };
 
-struct Chunk {  // 16 stored entries of one row, one per lane of the DPP row
-    int addr;   // in-window: byte offset of the operand row inside the LDS window; outside: the operand row
+struct Chunk {  // 16 entries outside the window, one per lane of the DPP row
+    int addr;   // the operand row
     float v, vt;
 };
 
-// Entry at position p of the index stream (idle lanes: operand row 0 with a zero weight).
+struct Chunk4 {  // 64 in-window entries, four consecutive ones per lane of the DPP row
+    int addr[4];  // byte offset of the operand row inside the LDS window
+    float v[4], vt[4];
+};
+
+// The entry streams of a tiling are laid out in the order the lanes consume them and padded with
+// zero-weight entries, so a lane fetches its share with one 16-byte load per stream and no bounds logic.
 template <bool DUAL>
-__device__ __forceinline__ Chunk load_entry(const SpmmArgs& a, const int p, const bool live) {
+__device__ __forceinline__ Chunk4 load_entries4(const SpmmArgs& a, const unsigned pos, const bool live) {
+    Chunk4 ck;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        ck.addr[q] = 0;
+        ck.v[q] = 0.f;
+        ck.vt[q] = 0.f;
+    }
+    if (live) {
+        const int4 c = *reinterpret_cast<const int4*>(a.s_addr + pos);
+        const float4 v = *reinterpret_cast<const float4*>(a.s_val + pos);
+        ck.addr[0] = c.x; ck.addr[1] = c.y; ck.addr[2] = c.z; ck.addr[3] = c.w;
+        ck.v[0] = v.x; ck.v[1] = v.y; ck.v[2] = v.z; ck.v[3] = v.w;
+        if (DUAL) {
+            const float4 vt = *reinterpret_cast<const float4*>(a.s_valT + pos);
+            ck.vt[0] = vt.x; ck.vt[1] = vt.y; ck.vt[2] = vt.z; ck.vt[3] = vt.w;
+        }
+    }
+    return ck;
+}
+
+template <bool DUAL>
+__device__ __forceinline__ Chunk load_outside(const SpmmArgs& a, const unsigned pos, const bool live) {
     Chunk ck;
     ck.addr = 0;
     ck.v = 0.f;
     ck.vt = 0.f;
     if (live) {
-        ck.addr = a.col[p];
-        ck.v = a.val[p];
-        if (DUAL) ck.vt = a.valT[p];
+        ck.addr = a.o_row[pos];
+        ck.v = a.o_val[pos];
+        if (DUAL) ck.vt = a.o_valT[pos];
     }
     return ck;
 }
@@ -301,21 +330,17 @@ __device__ __forceinline__ Chunk load_entry(const SpmmArgs& a, const int p, cons
 // The broadcasts are compiler-visible DPP operations (the wait states between a vector write and a DPP
 // read of the same register are inserted by the compiler) and fold into the instructions that use them:
 // the address is one v_add_u32 with a DPP source, and in the training pass the weight is two DPP moves
-// into one register, val into the lanes of the A half (DPP banks 0-1) and valT into the lanes of the
-// A^T half (banks 2-3): no select.
+// into one register: val to every lane, then valT over the lanes of the A^T half (DPP banks 2-3).
 template <int U>
 __device__ __forceinline__ int bcast_add(const int x, const int base) {  // lane U of the DPP row + this lane's base
     return __builtin_amdgcn_update_dpp(0, x, 0x150 + U, 0xf, 0xf, false) + base;
 }
 
 template <bool DUAL, int U>
-__device__ __forceinline__ float step_weight(const Chunk& ck) {
-    if (DUAL) {
-        int w = __builtin_amdgcn_update_dpp(0, __float_as_int(ck.v), 0x150 + U, 0xf, 0x3, false);
-        w = __builtin_amdgcn_update_dpp(w, __float_as_int(ck.vt), 0x150 + U, 0xf, 0xc, false);
-        return __int_as_float(w);
-    }
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ck.v), 0x150 + U, 0xf, 0xf, false));
+__device__ __forceinline__ float bcast_weight(const float v, const float vt) {
+    int w = __builtin_amdgcn_mov_dpp(__float_as_int(v), 0x150 + U, 0xf, 0xf, true);
+    if (DUAL) w = __builtin_amdgcn_update_dpp(w, __float_as_int(vt), 0x150 + U, 0xf, 0xc, false);
+    return __int_as_float(w);
 }
 
 template <int VEC>
@@ -324,35 +349,35 @@ __device__ __forceinline__ void vec_fma(float (&acc)[VEC], const float w, const 
     for (int q = 0; q < VEC; ++q) acc[q] = fmaf(w, x[q], acc[q]);
 }
 
-// Four in-window entries of each of the wave's four rows: the four LDS reads are requested together and
+// The four in-window entries held by lane L of each DPP row: the four LDS reads are requested together and
 // the products alternate between two accumulators.  lane_base = this lane's column offset inside a
 // window row + the window's LDS base address.
-template <int VEC, bool DUAL, int U>
-__device__ __forceinline__ void lds_step4(float (&acc0)[VEC], float (&acc1)[VEC], const Chunk& ck, const int lane_base) {
+template <int VEC, bool DUAL, int L>
+__device__ __forceinline__ void lds_group(float (&acc0)[VEC], float (&acc1)[VEC], const Chunk4& ck, const int lane_base) {
     typedef typename VecOf<VEC>::T V;
     typedef __attribute__((address_space(3))) const V LdsV;
-    const int a0 = bcast_add<U>(ck.addr, lane_base), a1 = bcast_add<U + 1>(ck.addr, lane_base);
-    const int a2 = bcast_add<U + 2>(ck.addr, lane_base), a3 = bcast_add<U + 3>(ck.addr, lane_base);
+    const int a0 = bcast_add<L>(ck.addr[0], lane_base), a1 = bcast_add<L>(ck.addr[1], lane_base);
+    const int a2 = bcast_add<L>(ck.addr[2], lane_base), a3 = bcast_add<L>(ck.addr[3], lane_base);
     const V x0 = *(LdsV*)(unsigned long)(unsigned)a0;
     const V x1 = *(LdsV*)(unsigned long)(unsigned)a1;
     const V x2 = *(LdsV*)(unsigned long)(unsigned)a2;
     const V x3 = *(LdsV*)(unsigned long)(unsigned)a3;
-    const float w0 = step_weight<DUAL, U>(ck), w1 = step_weight<DUAL, U + 1>(ck);
-    const float w2 = step_weight<DUAL, U + 2>(ck), w3 = step_weight<DUAL, U + 3>(ck);
+    const float w0 = bcast_weight<DUAL, L>(ck.v[0], ck.vt[0]), w1 = bcast_weight<DUAL, L>(ck.v[1], ck.vt[1]);
+    const float w2 = bcast_weight<DUAL, L>(ck.v[2], ck.vt[2]), w3 = bcast_weight<DUAL, L>(ck.v[3], ck.vt[3]);
     vec_fma<VEC>(acc0, w0, x0);
     vec_fma<VEC>(acc1, w1, x1);
     vec_fma<VEC>(acc0, w2, x2);
     vec_fma<VEC>(acc1, w3, x3);
 }
 
-// `steps` (1..16, wave-uniform) entries of an in-window chunk, four at a time (idle steps carry a zero weight)
+// The first `groups` (1..16, wave-uniform) lanes' entries of an in-window chunk (padding entries carry a zero weight)
 template <int VEC, bool DUAL>
-__device__ __forceinline__ void lds_chunk(float (&acc0)[VEC], float (&acc1)[VEC], const Chunk& ck, const int steps,
+__device__ __forceinline__ void lds_chunk(float (&acc0)[VEC], float (&acc1)[VEC], const Chunk4& ck, const int groups,
                                           const int lane_base) {
-    if (steps > 0) lds_step4<VEC, DUAL, 0>(acc0, acc1, ck, lane_base);
-    if (steps > 4) lds_step4<VEC, DUAL, 4>(acc0, acc1, ck, lane_base);
-    if (steps > 8) lds_step4<VEC, DUAL, 8>(acc0, acc1, ck, lane_base);
-    if (steps > 12) lds_step4<VEC, DUAL, 12>(acc0, acc1, ck, lane_base);
+#define SPARC_G(L) if (groups > L) lds_group<VEC, DUAL, L>(acc0, acc1, ck, lane_base);
+    SPARC_G(0) SPARC_G(1) SPARC_G(2) SPARC_G(3) SPARC_G(4) SPARC_G(5) SPARC_G(6) SPARC_G(7)
+    SPARC_G(8) SPARC_G(9) SPARC_G(10) SPARC_G(11) SPARC_G(12) SPARC_G(13) SPARC_G(14) SPARC_G(15)
+#undef SPARC_G
 }
 
 // Entries outside the window: the operand rows come from global memory (the slab's rows are 16 VEC floats
@@ -378,10 +403,10 @@ __device__ __forceinline__ Outside4<VEC> outside_issue4(const Chunk& ck, const f
 
 template <int VEC, bool DUAL, int U>
 __device__ __forceinline__ void outside_use4(float (&acc0)[VEC], float (&acc1)[VEC], const Chunk& ck, const Outside4<VEC>& o) {
-    vec_fma<VEC>(acc0, step_weight<DUAL, U>(ck), o.x[0]);
-    vec_fma<VEC>(acc1, step_weight<DUAL, U + 1>(ck), o.x[1]);
-    vec_fma<VEC>(acc0, step_weight<DUAL, U + 2>(ck), o.x[2]);
-    vec_fma<VEC>(acc1, step_weight<DUAL, U + 3>(ck), o.x[3]);
+    vec_fma<VEC>(acc0, bcast_weight<DUAL, U>(ck.v, ck.vt), o.x[0]);
+    vec_fma<VEC>(acc1, bcast_weight<DUAL, U + 1>(ck.v, ck.vt), o.x[1]);
+    vec_fma<VEC>(acc0, bcast_weight<DUAL, U + 2>(ck.v, ck.vt), o.x[2]);
+    vec_fma<VEC>(acc1, bcast_weight<DUAL, U + 3>(ck.v, ck.vt), o.x[3]);
 }
 
 template <int VEC, bool DUAL, int U>
@@ -404,15 +429,16 @@ __device__ __forceinline__ void outside_chunk(float (&acc0)[VEC], float (&acc1)[
 template <int VEC, bool DUAL, int EPI>
 __global__ __launch_bounds__(WIN_MAX_THREADS) void spmm_win(const SpmmArgs a) {
     extern __shared__ float4 tile[];  // [window rows][16 lanes][VEC floats]
+    __shared__ int4 info[WIN_MAX_RECORDS];  // the slot records of this workgroup
     typedef typename VecOf<VEC>::T V;
     constexpr int RW = 16 * VEC;      // floats per slab row
     constexpr int ROWB = RW * 4;      // bytes per slab row
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, and known to be
     const int g = lane >> 4, lr = lane & 15;
     const int32_t* d = a.desc + static_cast<int64_t>(blockIdx.x) * 8;
-    const int q_begin = d[0], q_end = d[1], w0 = d[2], wn = d[3] - d[2], slab = d[4], n_long = d[5];
-    const int nq = q_end - q_begin;
-    if (nq <= 0) {  // padding descriptor
+    const int s_begin = d[0], s_end = d[1], w0 = d[2], wn = d[3] - d[2], slab = d[4], n_long = d[5];
+    if (s_end <= s_begin) {  // padding descriptor
         if ((EPI == EPI_LAP_SINGLE || EPI == EPI_LAP_DUAL) && threadIdx.x == 0) a.loss_part[blockIdx.x] = 0.0;
         return;
     }
@@ -424,93 +450,92 @@ __global__ __launch_bounds__(WIN_MAX_THREADS) void spmm_win(const SpmmArgs a) {
     const float* __restrict__ X0s = a.X0 ? a.X0 + slab_off + lr * VEC : nullptr;
     float* __restrict__ outs = a.out ? a.out + slab_off + lr * VEC : nullptr;
 
-    // A wave owns slots wave, wave + nwaves, ... sorted by work (longest first) and dealt in serpentine
-    // order.  The first n_long records are long rows, each worked on by the whole wave (DPP row g takes
-    // entries g, g + 4, ...; the four partial sums are merged at the end); the other records are taken four
-    // at a time, one row per DPP row.  Record = {row, p0, n_in, n_before << 16 | n_after}: the row's stored
-    // entries are [p0, p0 + n_before) before the window, then n_in inside it, then n_after behind it.
-    const int nslots = n_long + (nq - n_long + 3) / 4;
-    const int4* __restrict__ rec = reinterpret_cast<const int4*>(a.rowinfo) + q_begin;
-    auto slot_of = [&](const int round) { return round * nwaves + ((round & 1) ? nwaves - 1 - wave : wave); };
-    auto load_record = [&](const int slot) {
-        const int qi = slot < n_long ? slot : n_long + (slot - n_long) * 4 + g;
-        int4 ri = make_int4(-1, 0, 0, 0);
-        if (slot < nslots && qi < nq) ri = rec[qi];
-        return ri;
-    };
-    struct Slot {
-        int4 ri;
-        Chunk c0, c1, o0;  // the first two in-window chunks and the first outside chunk
-    };
-    // The entry chunks of a slot are requested two slots ahead, its record three: global-memory latency
-    // hides behind LDS work (for the first slots: behind the staging of the window).
-    auto with_chunks = [&](const int4 ri, const int slot) {
-        Slot s;
-        const bool lng = slot < n_long;
-        s.ri = ri;
-        const int off = lng ? lr * 4 + g : lr;  // entry of this lane inside a chunk
-        const int nb = ri.w >> 16, no = nb + (ri.w & 0xffff);
-        const int lo = ri.y + nb, hi = lo + ri.z;
-        s.c0 = load_entry<DUAL>(a, lo + off, off < ri.z);
-        s.c0.addr = (s.c0.addr - (off < ri.z ? w0 : 0)) * ROWB;
-        const int off1 = off + (lng ? 64 : 16);
-        s.c1 = load_entry<DUAL>(a, lo + off1, off1 < ri.z);
-        s.c1.addr = (s.c1.addr - (off1 < ri.z ? w0 : 0)) * ROWB;
-        s.o0 = load_entry<DUAL>(a, off < nb ? ri.y + off : hi + (off - nb), off < no);
-        return s;
-    };
-    const int4 r0 = load_record(slot_of(0)), r1 = load_record(slot_of(1));
-    int4 ri2 = load_record(slot_of(2));
-
-    {   // stage the window: one wave instruction moves 64 x 16 bytes to LDS base + lane * 16
+    long long t_start = 0, t_bar = 0;
+    if (a.stamps) t_start = __builtin_readcyclecounter();
+    const int nrec = (s_end - s_begin) * 4;
+    {   // stage the window and the slot records with asynchronous global->LDS copies (no register round trip):
+        // one wave instruction moves 64 x 16 bytes to LDS base + lane * 16
         const float* src = a.Xg + slab_off + static_cast<int64_t>(w0) * RW;
-        const int n16 = wn * (ROWB / 16);
+        const int n16 = (a.dbg & 4) ? 0 : wn * (ROWB / 16);
         for (int base = wave * 64; base < n16; base += blockDim.x) {
             const int i = base + lane;
             if (i < n16)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 4),
                                                  (__attribute__((address_space(3))) void*)(tile + base), 16, 0, 0);
         }
+        const int4* rsrc = reinterpret_cast<const int4*>(a.rowinfo) + static_cast<int64_t>(s_begin) * 4;
+        for (int base = wave * 64; base < nrec; base += blockDim.x) {
+            const int i = base + lane;
+            if (i < nrec)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rsrc + i),
+                                                 (__attribute__((address_space(3))) void*)(info + base), 16, 0, 0);
+        }
     }
-    Slot cur = with_chunks(r0, slot_of(0)), nxt = with_chunks(r1, slot_of(1));
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's copies into LDS have landed
     __syncthreads();                     // ... and so have everybody else's
+    if (a.stamps) t_bar = __builtin_readcyclecounter();
+
+    // A wave owns slots wave, wave + nwaves, ... sorted by work (longest first) and dealt in serpentine
+    // order.  A slot is four rows, one per DPP row, or (the first n_long slots) one long row worked on by the
+    // whole wave, whose four partial sums are merged at the end.  Record of (slot, DPP row) =
+    // {row, position of the slot's in-window entries, position of its outside entries, L | O << 16}: every
+    // lane lr < L holds four in-window entries, every lane lr < O one outside entry (both streams are padded
+    // with zero-weight entries up to these wave-uniform counts).
+    const int nslots = (a.dbg & 1) ? 0 : s_end - s_begin;
+    auto slot_of = [&](const int round) { return round * nwaves + ((round & 1) ? nwaves - 1 - wave : wave); };
+    struct Slot {
+        int4 ri;
+        Chunk4 c0;  // the first in-window chunk: all of a short row
+        Chunk o0;   // the first outside chunk
+        float x0[VEC];  // the row's own operand of the epilogue
+    };
+    const bool has_out = d[6] != 0;  // any of this workgroup's rows has entries outside the window
+    const unsigned lane4 = (lr * 4 + g) * 4, lane1 = lr * 4 + g;  // this lane's place inside a chunk of either stream
+    // Everything a slot reads from global memory is requested one slot ahead: global-memory latency hides
+    // behind the LDS work of the slot before.
+    auto fetch = [&](Slot& s, const int slot) {
+        int4 ri = make_int4(-1, 0, 0, 0);
+        if (slot < nslots) ri = info[slot * 4 + g];
+        s.ri = ri;
+        s.c0 = load_entries4<DUAL>(a, static_cast<unsigned>(ri.y) + lane4, lr < (ri.w & 0xffff));
+        s.o0.addr = 0; s.o0.v = 0.f; s.o0.vt = 0.f;
+        if (has_out) s.o0 = load_outside<DUAL>(a, static_cast<unsigned>(ri.z) + lane1, lr < (ri.w >> 16));
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) s.x0[q] = 0.f;
+        if (EPI != EPI_STORE) load_vec<VEC>(s.x0, X0s + static_cast<int64_t>(ri.x >= 0 ? ri.x : 0) * RW);
+    };
 
     const int lane_base = lr * (VEC * 4) + (int)(unsigned long)(__attribute__((address_space(3))) const char*)tile;
     const LapConst<VEC> lc = lap_const<VEC, EPI>(a, cl, right);
     double wloss = 0.0;
-    for (int round = 0; round * nwaves < nslots; ++round) {  // wave-uniform
-        const int slot = slot_of(round);
-        const Slot nn = with_chunks(ri2, slot_of(round + 2));
-        ri2 = load_record(slot_of(round + 3));
+    auto work = [&](const Slot& cur, const int slot) {
         const bool lng = slot < n_long;  // wave-uniform
         const int4 ri = cur.ri;
         const bool valid = ri.x >= 0;
-        const int nb = ri.w >> 16, no = nb + (ri.w & 0xffff);
-        const int lo = ri.y + nb, hi = lo + ri.z;
-        // rows are sorted by in-window length: DPP row 0 holds the longest of the four
-        const int nmax = __builtin_amdgcn_readfirstlane(ri.z);
-        const int steps = lng ? (nmax + 3) >> 2 : nmax;
-        const int cstride = lng ? 64 : 16;  // entries per chunk
-        const int off = lng ? lr * 4 + g : lr;
-        int no_max = max(max(__builtin_amdgcn_readlane(no, 0), __builtin_amdgcn_readlane(no, 16)),
-                         max(__builtin_amdgcn_readlane(no, 32), __builtin_amdgcn_readlane(no, 48)));
-        const int osteps = lng ? (no_max + 3) >> 2 : no_max;
-        // the epilogue's own-row operands and the first four outside operand rows travel behind the LDS work
-        const RowPre<VEC> pre = row_preload<VEC, EPI>(a, valid ? ri.x : 0, X0s ? X0s + static_cast<int64_t>(valid ? ri.x : 0) * RW : nullptr);
-        Outside4<VEC> o4;
-        if (osteps > 0) o4 = outside_issue4<VEC, 0>(cur.o0, Xs);
+        const int groups = (a.dbg & 2) ? 0 : __builtin_amdgcn_readfirstlane(ri.w & 0xffff);
+        const int64_t row = valid ? ri.x : 0;
+        RowPre<VEC> pre = row_preload<VEC, EPI_STORE>(a, row, nullptr);  // the per-row constants arrive behind the LDS work
+        if (EPI == EPI_LAP_SINGLE || EPI == EPI_LAP_DUAL) {
+            pre.rc0 = *reinterpret_cast<const float4*>(a.rowc + row * SPARC_ROWC);
+            pre.rc1 = *reinterpret_cast<const float4*>(a.rowc + row * SPARC_ROWC + 4);
+        }
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) pre.x0[q] = cur.x0[q];
         float acc[VEC], acc1[VEC];
 #pragma unroll
         for (int q = 0; q < VEC; ++q) acc[q] = acc1[q] = 0.f;
-        if (steps > 0) lds_chunk<VEC, DUAL>(acc, acc1, cur.c0, min(steps, 16), lane_base);
-        if (steps > 16) {
-            Chunk ck = cur.c1;
-            for (int c = 1; c * 16 < steps; ++c) {  // the next chunk is requested before this one is worked on
-                const int offn = (c + 1) * cstride + off;
-                Chunk cn = load_entry<DUAL>(a, lo + offn, offn < ri.z);
-                cn.addr = (cn.addr - (offn < ri.z ? w0 : 0)) * ROWB;
-                lds_chunk<VEC, DUAL>(acc, acc1, ck, min(steps - c * 16, 16), lane_base);
+        Outside4<VEC> o4;
+        int osteps = 0;
+        if (has_out) {  // the first four outside operand rows travel behind the LDS work
+            osteps = __builtin_amdgcn_readfirstlane(ri.w >> 16);
+            if (osteps > 0) o4 = outside_issue4<VEC, 0>(cur.o0, Xs);
+        }
+        if (groups > 0) lds_chunk<VEC, DUAL>(acc, acc1, cur.c0, min(groups, 16), lane_base);
+        if (groups > 16) {  // rows of more than 256 in-window entries: the next chunk is requested before this one is used
+            Chunk4 ck = load_entries4<DUAL>(a, static_cast<unsigned>(ri.y) + 256 + lane4, lr + 16 < groups);
+            for (int c = 1; c * 16 < groups; ++c) {
+                const Chunk4 cn = load_entries4<DUAL>(a, static_cast<unsigned>(ri.y) + (c + 1) * 256 + lane4, lr + (c + 1) * 16 < groups);
+                lds_chunk<VEC, DUAL>(acc, acc1, ck, min(groups - c * 16, 16), lane_base);
                 ck = cn;
             }
         }
@@ -518,8 +543,7 @@ __global__ __launch_bounds__(WIN_MAX_THREADS) void spmm_win(const SpmmArgs a) {
             outside_use4<VEC, DUAL, 0>(acc, acc1, cur.o0, o4);
             outside_chunk<VEC, DUAL>(acc, acc1, cur.o0, 4, min(osteps, 16), Xs);
             for (int c = 1; c * 16 < osteps; ++c) {
-                const int t = c * cstride + off;
-                const Chunk ck = load_entry<DUAL>(a, t < nb ? ri.y + t : hi + (t - nb), t < no);
+                const Chunk ck = load_outside<DUAL>(a, static_cast<unsigned>(ri.z) + c * 64 + lane1, lr + c * 16 < osteps);
                 outside_chunk<VEC, DUAL>(acc, acc1, ck, 0, min(osteps - c * 16, 16), Xs);
             }
         }
@@ -533,12 +557,24 @@ __global__ __launch_bounds__(WIN_MAX_THREADS) void spmm_win(const SpmmArgs a) {
             }
         }
         const bool owner = valid && (!lng || g == 0);
-        row_epilogue<VEC, DUAL, EPI>(a, valid ? ri.x : 0, lane, owner, 8, cl, right, pre, lc, acc,
-                                     outs ? outs + static_cast<int64_t>(valid ? ri.x : 0) * RW : nullptr, 0, wloss);
-        cur = nxt;
-        nxt = nn;
+        row_epilogue<VEC, DUAL, EPI>(a, row, lane, owner, 8, cl, right, pre, lc, acc, outs ? outs + row * RW : nullptr, 0,
+                                     wloss);
+    };
+    // two slots in turn, so that no register that a load is still writing has to be copied
+    Slot sa, sb;
+    fetch(sa, slot_of(0));
+    for (int round = 0; round * nwaves < nslots; round += 2) {  // wave-uniform
+        fetch(sb, slot_of(round + 1));
+        work(sa, slot_of(round));
+        if ((round + 1) * nwaves >= nslots) break;
+        fetch(sa, slot_of(round + 2));
+        work(sb, slot_of(round + 1));
     }
 
+    if (a.stamps && lane == 0) {  // developer timeline: per wave {start, after the barrier, end, slots}
+        long long* st = a.stamps + (static_cast<int64_t>(blockIdx.x) * 16 + wave) * 4;
+        st[0] = t_start; st[1] = t_bar; st[2] = __builtin_readcyclecounter(); st[3] = nslots;
+    }
     if (EPI == EPI_LAP_SINGLE || EPI == EPI_LAP_DUAL) {
         __shared__ double wl[WIN_MAX_THREADS / 64];
         wloss = wave_sum(wloss);
@@ -687,6 +723,8 @@ int launch_rows(const SpmmArgs& a, hipStream_t stream) {
     return SPARC_OK;
 }
 
+long long* g_stamps = nullptr;  // developer timeline buffer (SPARC_DBG & 64), set by sparc_debug_stamps
+
 // Per device and per instantiation: allow the large dynamic LDS allocation.
 template <int VEC, bool DUAL, int EPI>
 int configure_win() {
@@ -711,7 +749,14 @@ int launch_win(const SpmmArgs& a, hipStream_t stream) {
     if (lds > SPARC_TILE_LDS_BYTES || a.threads < 64 || a.threads > WIN_MAX_THREADS || a.threads % 64) return SPARC_ERR_ARG;
     const int rc = configure_win<VEC, DUAL, EPI>();
     if (rc) return rc;
-    hipLaunchKernelGGL((spmm_win<VEC, DUAL, EPI>), dim3(static_cast<unsigned>(a.ndesc)), dim3(a.threads), lds, stream, a);
+    SpmmArgs b = a;
+    static const int dbg = [] {  // developer switch for kernel ablation timings, read once
+        const char* e = getenv("SPARC_DBG");
+        return e ? atoi(e) : 0;
+    }();
+    b.dbg = dbg;
+    b.stamps = (dbg & 64) && EPI == EPI_ADD_X0 ? g_stamps : nullptr;
+    hipLaunchKernelGGL((spmm_win<VEC, DUAL, EPI>), dim3(static_cast<unsigned>(a.ndesc)), dim3(a.threads), lds, stream, b);
     SPARC_CHECK_LAUNCH();
     return SPARC_OK;
 }
@@ -751,8 +796,11 @@ int set_tiling(SpmmArgs& a, const sparc_tiling_t* t, int64_t m, bool dual, int k
         static_cast<size_t>(t->rows) * 64 * t->vec > SPARC_TILE_LDS_BYTES || (t->dual != 0) != dual || t->kp != kp ||
         kp % hw != 0 || t->threads < 64 || t->threads > WIN_MAX_THREADS || t->threads % 64)
         return SPARC_ERR_ARG;
+    if (!t->s_addr || !t->s_val || (dual && !t->s_valT) || !t->o_row || !t->o_val || (dual && !t->o_valT)) return SPARC_ERR_ARG;
     a.desc = t->buf;
-    a.rowinfo = t->buf + static_cast<int64_t>(t->ndesc) * 8;  // the row records follow the descriptors
+    a.rowinfo = t->buf + static_cast<int64_t>(t->ndesc) * 8;  // the slot records follow the descriptors
+    a.s_addr = t->s_addr; a.s_val = t->s_val; a.s_valT = t->s_valT;
+    a.o_row = t->o_row; a.o_val = t->o_val; a.o_valT = t->o_valT;
     a.ndesc = t->ndesc;
     a.tile_rows = t->rows;
     a.vec = t->vec;
@@ -774,6 +822,11 @@ int sparc_spmm_launch(int epi, int width, const SpmmArgs& a, hipStream_t stream)
         case EPI_PREP_ACC: return width == 64 && !a.desc ? launch_single<EPI_PREP_ACC>(64, a, stream) : SPARC_ERR_ARG;
     }
     return SPARC_ERR_ARG;
+}
+
+extern "C" int sparc_debug_stamps(long long* buf) {  // not part of the public header: kernel timeline experiments
+    g_stamps = buf;
+    return SPARC_OK;
 }
 
 extern "C" int sparc_profile_begin(int epilogue, int max_launches) {
@@ -813,7 +866,7 @@ extern "C" int sparc_spmm(int64_t m, int64_t nnz, const int64_t* rowptr, const i
                           sparc_stream_t stream) {
     if (m < 0 || nnz < 0 || !rowptr || (nnz > 0 && (!colidx || !val)) || !X || !Z) return SPARC_ERR_ARG;
     SpmmArgs a = {};
-    a.m = m; a.rowptr = rowptr; a.col = colidx; a.val = val; a.valT = val;
+    a.m = m; a.nnz = nnz; a.rowptr = rowptr; a.col = colidx; a.val = val; a.valT = val;
     a.Xg = X; a.X0 = X0; a.out = Z;
     a.kp = width;
     // a tiled plain product works on one slab: the row-major operand is the slab
@@ -883,7 +936,7 @@ extern "C" int sparc_lap_fwd(int64_t m, int64_t nnz, const int64_t* rowptr, cons
     if (!ws || !c.ok()) return SPARC_ERR_WS;
 
     SpmmArgs a = {};
-    a.m = m; a.rowptr = rowptr; a.col = colidx; a.val = val; a.valT = valT ? valT : val;
+    a.m = m; a.nnz = nnz; a.rowptr = rowptr; a.col = colidx; a.val = val; a.valT = valT ? valT : val;
     a.rowc = rowc; a.M12 = M12; a.loss_part = loss_part; a.gradY = gradY; a.ldy = ldy; a.k = k; a.kp = kp;
     a.inv_m = static_cast<float>(1.0 / static_cast<double>(m));
     int rcode = set_tiling(a, tiling, m, dual, kp);

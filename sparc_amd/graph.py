@@ -18,7 +18,7 @@ from ._lib import check, lib
 EPS_BACKGROUND = 1e-6  # src/SpectralTrainer.py:288
 TILE_LDS_BYTES = 128 * 1024   # LDS budget of one window (rows * 64 * vec bytes)
 TILE_MAX_ROWS = 512           # rows of one window
-TILE_LONG_ROW = 64            # SPARC_TILE_LONG_ROW: longer rows get a whole wavefront
+TILE_LONG_ROW = 128           # SPARC_TILE_LONG_ROW: rows with more in-window entries get a whole wavefront
 TILE_MAX_RUN = 65535          # entries of one row before / behind its window
 TILE_MAX_OUTSIDE_SHARE = 0.5  # a batch with a larger share of its entries outside the windows is not tiled
 N_CU = 256
@@ -54,36 +54,75 @@ def plan_windows(m: int, cluster_sizes=None, max_rows: int = TILE_MAX_ROWS):
     return [(a, b) for a, b in wins if b > a]
 
 
-def plan_tiles(windows, p0: np.ndarray, lo: np.ndarray, hi: np.ndarray, p1: np.ndarray, n_slabs: int,
-               threads: int = 512, target_wgs: int = 2 * N_CU):
-    """The tiling buffer of the windowed kernel (layout: include/sparc_hip.h): descriptors int32[.][8] and
-    row records int32[m][4].  Row i stores its entries at [p0, p1); those whose column lies in the
-    row's window are [lo, hi).  Every window's rows are sorted by in-window length (longest first)
-    and dealt round-robin to J parts so that windows x slabs x J fills the chip with equal work."""
+TILE_MAX_SLOTS = 128          # slots of one workgroup (four records each: SPARC_TILE_MAX_RECORDS / 4)
+
+
+def plan_tiles(windows, n_in: np.ndarray, n_out: np.ndarray, n_slabs: int, threads: int = 512,
+               target_wgs: int = 2 * N_CU):
+    """Work plan of the windowed kernel (layout: include/sparc_hip.h).  n_in / n_out: per row, the number of
+    stored entries whose column lies inside / outside the row's window.  Every window's rows are sorted
+    by n_in (longest first) and dealt round-robin to J parts so that windows x slabs x J fills the chip
+    with equal work; a part's rows are cut into slots: one row of more than TILE_LONG_ROW in-window
+    entries, or four shorter rows.  Returns a dict: desc int32[.][8] (one per workgroup, XCD-aligned),
+    slot_rows int32[nslots][4] (-1: none), slot_L / slot_O (lanes' worth of in-window entries, four per
+    lane, and of outside entries, one per lane), slot_base / slot_obase (positions in the two entry
+    streams), stream_len / ostream_len, and per row its slot, DPP row and long flag."""
     nw = len(windows)
     J = max(1, target_wgs // max(nw * n_slabs, 1))
-    desc, recs = [], []
-    q = 0
-    length = hi - lo
-    packed = ((lo - p0) << 16) | (p1 - hi)
     min_rows = threads // 16                      # one row per 16-lane group of the workgroup
-
+    m = len(n_in)
+    desc, slot_rows = [], []
     for (a, b) in windows:
         rows = np.arange(a, b)
-        order = rows[np.argsort(-length[rows], kind="stable")]
+        order = rows[np.argsort(-n_in[rows], kind="stable")]
         parts = max(1, min(J, (len(order) + min_rows - 1) // min_rows))
+        while True:                                # keep every part within the records a workgroup can hold
+            worst = 0
+            for j in range(parts):
+                mine = order[j::parts]
+                nl = int((n_in[mine] > TILE_LONG_ROW).sum())
+                worst = max(worst, nl + (len(mine) - nl + 3) // 4)
+            if worst <= TILE_MAX_SLOTS:
+                break
+            parts += 1
         for j in range(parts):
             mine = order[j::parts]
             if len(mine) == 0:
                 continue
-            recs.append(np.stack([mine, p0[mine], length[mine], packed[mine]], axis=1))
-            n_long = int((length[mine] > TILE_LONG_ROW).sum())
+            nl = int((n_in[mine] > TILE_LONG_ROW).sum())
+            s0 = len(slot_rows)
+            for r in mine[:nl]:
+                slot_rows.append((r, -1, -1, -1))
+            rest = mine[nl:]
+            for i in range(0, len(rest), 4):
+                quad = list(rest[i:i + 4]) + [-1] * (4 - len(rest[i:i + 4]))
+                slot_rows.append(tuple(quad))
+            s1 = len(slot_rows)
+            has_out = int(n_out[mine].max() > 0)
             for s_ in range(n_slabs):
-                desc.append((q, q + len(mine), a, b, s_, n_long, 0, 0))
-            q += len(mine)
-    desc = np.asarray(_xcd_align(desc), dtype=np.int32).reshape(-1, 8)
-    recs = np.concatenate(recs, axis=0).astype(np.int32) if recs else np.zeros((0, 4), np.int32)
-    return desc, recs
+                desc.append((s0, s1, a, b, s_, nl, has_out, 0))
+    slot_rows = np.asarray(slot_rows, dtype=np.int64).reshape(-1, 4)
+    ns = slot_rows.shape[0]
+    first = slot_rows[:, 0]
+    is_long_slot = slot_rows[:, 1] < 0
+    is_long_slot &= n_in[first] > TILE_LONG_ROW
+    safe = np.where(slot_rows >= 0, slot_rows, 0)
+    nin_s = np.where(slot_rows >= 0, n_in[safe], 0)
+    nout_s = np.where(slot_rows >= 0, n_out[safe], 0)
+    groups = (nin_s.max(axis=1) + 3) // 4                                  # the first row is the longest
+    slot_L = np.where(is_long_slot, (groups + 3) // 4, groups)
+    slot_O = np.where(is_long_slot, (nout_s[:, 0] + 3) // 4, nout_s.max(axis=1))
+    slot_base = np.concatenate([[0], np.cumsum(slot_L * 16)])
+    slot_obase = np.concatenate([[0], np.cumsum(slot_O * 4)])
+    row_slot = np.zeros(m, np.int64); row_g = np.zeros(m, np.int64)
+    for gi in range(4):
+        ok = slot_rows[:, gi] >= 0
+        row_slot[slot_rows[ok, gi]] = np.nonzero(ok)[0]
+        row_g[slot_rows[ok, gi]] = gi
+    return {"desc": np.asarray(_xcd_align(desc), dtype=np.int32).reshape(-1, 8), "slot_rows": slot_rows.astype(np.int32),
+            "slot_L": slot_L, "slot_O": slot_O, "slot_base": slot_base[:-1], "slot_obase": slot_obase[:-1],
+            "stream_len": int(slot_base[-1]), "ostream_len": int(slot_obase[-1]),
+            "row_slot": row_slot, "row_g": row_g, "row_long": is_long_slot[row_slot] if ns else np.zeros(m, bool)}
 
 
 N_XCD = 8  # workgroup b runs on XCD b % 8 (round-robin dispatch), and every XCD has its own L2
@@ -103,10 +142,10 @@ def _xcd_align(desc):
         groups.setdefault(key, []).append(d)
     bins = [[] for _ in range(N_XCD)]
     load = [0] * N_XCD
-    for key, ds in sorted(groups.items(), key=lambda kv: -sum(d[1] - d[0] for d in kv[1])):
+    for key, ds in sorted(groups.items(), key=lambda kv: -(kv[0][1] - kv[0][0])):
         x = min(range(N_XCD), key=lambda i: (load[i], len(bins[i])))
         bins[x].extend(ds)
-        load[x] += sum(d[1] - d[0] for d in ds)
+        load[x] += key[1] - key[0]
     depth = max(len(b) for b in bins)
     empty = (0, 0, 0, 0, 0, 0, 0, 0)
     out = []
@@ -277,24 +316,75 @@ class ClusterBatch:
             self._tiles[key] = self._plan(vec, kp, n_slabs, bool(training), threads, target)
         return self._tiles[key]
 
-    def _plan(self, vec, kp, n_slabs, dual, threads, target):
+    def _plan(self, vec, kp, n_slabs, dual, threads, target, mirrored=False):
+        """Tiling for one kernel geometry: work descriptors and slot records (planned on the host) and the
+        entry streams in consumption order (scattered on the device).  mirrored: bake the mirrored values
+        into the single-width stream (for A^T X)."""
         if self.nnz >= 2 ** 31 or self.m == 0:
             return None
         rows = max(b - a for a, b in self._windows)
         if rows * 64 * vec > TILE_LDS_BYTES:
             return None
         p0, lo, hi, p1 = self._in_window_ranges()
-        before, after = lo - p0, p1 - hi
-        if len(before) and (before.max() > TILE_MAX_RUN or after.max() > TILE_MAX_RUN):
+        n_in, n_out = hi - lo, (lo - p0) + (p1 - hi)
+        if n_out.sum() > TILE_MAX_OUTSIDE_SHARE * max(self.nnz, 1):
             return None
-        if (before.sum() + after.sum()) > TILE_MAX_OUTSIDE_SHARE * max(self.nnz, 1):
+        pl = plan_tiles(self._windows, n_in, n_out, n_slabs, threads, target)
+        if len(pl["slot_L"]) and (pl["slot_L"].max() > 0xFFFF or pl["slot_O"].max() > 0x7FFF) or \
+                max(pl["stream_len"], pl["ostream_len"]) >= 2 ** 31 - 4096:
             return None
-        desc, recs = plan_tiles(self._windows, p0, lo, hi, p1, n_slabs, threads, target)
-        assert recs.shape[0] == self.m
-        buf = torch.from_numpy(np.concatenate([desc.ravel(), recs.ravel()]).astype(np.int32)).to(self.device)
-        t = _lib.Tiling(buf.data_ptr(), int(desc.shape[0]), int(rows), vec, threads, kp, int(dual))
-        t.keep = buf             # the struct points into this tensor
-        t.desc = desc
+        dev, m = self.device, self.m
+        rec = np.empty((pl["slot_rows"].shape[0], 4, 4), np.int32)
+        rec[:, :, 0] = pl["slot_rows"]
+        rec[:, :, 1] = pl["slot_base"][:, None]
+        rec[:, :, 2] = pl["slot_obase"][:, None]
+        rec[:, :, 3] = (pl["slot_L"] | (pl["slot_O"] << 16))[:, None]
+        buf = torch.from_numpy(np.concatenate([pl["desc"].ravel(), rec.ravel()]).astype(np.int32)).to(dev)
+        # per-entry positions in the streams
+        up = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.int64)).to(dev)
+        wb = np.empty(m, np.int64)
+        for a, b in self._windows:
+            wb[a:b] = a
+        r_p0, r_nb, r_ni = up(p0), up(lo - p0), up(n_in)
+        r_base, r_obase = up(pl["slot_base"][pl["row_slot"]]), up(pl["slot_obase"][pl["row_slot"]])
+        r_g, r_long, r_w0 = up(pl["row_g"]), up(pl["row_long"]).bool(), up(wb)
+        counts = self.rowptr[1:] - self.rowptr[:-1]
+        row = torch.repeat_interleave(torch.arange(m, device=dev), counts)
+        e = torch.arange(self.nnz, device=dev, dtype=torch.int64) - r_p0[row]
+        ein = e - r_nb[row]
+        inside = (ein >= 0) & (ein < r_ni[row])
+        g, lng = r_g[row], r_long[row]
+        pos_in = r_base[row] + torch.where(lng, ein, (torch.div(ein, 4, rounding_mode="floor") * 4 + g) * 4 + ein % 4)
+        t = torch.where(ein < 0, e, e - r_ni[row])
+        pos_out = r_obase[row] + torch.where(lng, t, t * 4 + g)
+        col = self.colidx.to(torch.int64)
+        valT = self.valT if self.valT is not None else self.val
+        v_main, v_mirr = (valT, self.val) if mirrored else (self.val, valT)
+        n_s, n_o = pl["stream_len"] + 16, pl["ostream_len"] + 16
+        s_addr = torch.zeros(n_s, dtype=torch.int32, device=dev)
+        s_val = torch.zeros(n_s, dtype=torch.float32, device=dev)
+        o_row = torch.zeros(n_o, dtype=torch.int32, device=dev)
+        o_val = torch.zeros(n_o, dtype=torch.float32, device=dev)
+        pi, po = pos_in[inside], pos_out[~inside]
+        s_addr[pi] = ((col[inside] - r_w0[row[inside]]) * (64 * vec)).to(torch.int32)
+        s_val[pi] = v_main[inside]
+        o_row[po] = self.colidx[~inside]
+        o_val[po] = v_main[~inside]
+        s_valT = o_valT = None
+        if dual:
+            if self.valT is None:
+                s_valT, o_valT = s_val, o_val
+            else:
+                s_valT = torch.zeros(n_s, dtype=torch.float32, device=dev)
+                o_valT = torch.zeros(n_o, dtype=torch.float32, device=dev)
+                s_valT[pi] = v_mirr[inside]
+                o_valT[po] = v_mirr[~inside]
+        t = _lib.Tiling(buf.data_ptr(), int(pl["desc"].shape[0]), int(rows), vec, threads, kp, int(dual),
+                        s_addr.data_ptr(), s_val.data_ptr(), s_valT.data_ptr() if s_valT is not None else None,
+                        o_row.data_ptr(), o_val.data_ptr(), o_valT.data_ptr() if o_valT is not None else None)
+        t.keep = (buf, s_addr, s_val, s_valT, o_row, o_val, o_valT)   # the struct points into these tensors
+        t.plan = pl
+        t.desc = pl["desc"]
         return t
 
     def _prepare(self, eps):
@@ -359,10 +449,11 @@ class ClusterBatch:
         if tiled:
             if width not in (32, 64):
                 raise ValueError("the windowed kernel takes a plain product of width 32 or 64")
-            key = ("spmm", width)
+            mirrored = transpose and self.valT is not None
+            key = ("spmm", width, mirrored)
             if key not in self._tiles:
                 self._tiles[key] = self._plan(width // 16, width, 1, False, 512 if width == 32 else 1024,
-                                              2 * N_CU if width == 32 else N_CU)
+                                              2 * N_CU if width == 32 else N_CU, mirrored=mirrored)
             t = self._tiles[key]
             if t is None:
                 raise ValueError("this batch has no tiling")

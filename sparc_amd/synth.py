@@ -21,31 +21,49 @@ SHAPES = {
 def planted_cluster_graph(n: int, n_edges: int, n_clusters: int, device, frac_in_cluster: float = 0.7,
                           skew: float = 2.0, seed: int = 0):
     """Symmetric adjacency A + A^T + I (values 1, unit diagonal, as src/utils.py:238-243 builds it)
-    with `frac_in_cluster` of the edges inside contiguous node ranges (the planted clusters) and
-    the rest uniform; `skew` > 1 concentrates endpoints on the first nodes of a cluster
-    (heavier-tailed degrees).  Returns (DeviceGraph, bounds int64[n_clusters+1])."""
+    with EXACTLY n_edges distinct undirected edges (when the graph can hold them): `frac_in_cluster`
+    of the draws fall inside contiguous node ranges (the planted clusters), the rest are uniform;
+    `skew` > 1 concentrates endpoints on the first nodes of a cluster (heavier-tailed degrees).
+    Repeated draws are dropped and drawn again (from the third round on uniformly: a cluster that is
+    already complete cannot take more), and a surplus is thinned at random.
+    Returns (DeviceGraph, bounds int64[n_clusters+1])."""
     dev = torch.device(device)
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
     bounds = torch.div(torch.arange(n_clusters + 1, device=dev, dtype=torch.int64) * n, n_clusters, rounding_mode="floor")
-    e_in = int(n_edges * frac_in_cluster)
-    e_out = n_edges - e_in
-    c = torch.randint(n_clusters, (e_in,), generator=gen, device=dev)
-    lo = bounds[c]
-    sz = (bounds[c + 1] - lo).double()
-    u = lo + (torch.rand(e_in, generator=gen, device=dev, dtype=torch.float64).pow(skew) * sz).long()
-    v = lo + (torch.rand(e_in, generator=gen, device=dev, dtype=torch.float64).pow(skew) * sz).long()
-    uo = torch.randint(n, (e_out,), generator=gen, device=dev)
-    vo = torch.randint(n, (e_out,), generator=gen, device=dev)
-    u = torch.cat([u, uo]).clamp_(max=n - 1)
-    v = torch.cat([v, vo]).clamp_(max=n - 1)
-    del uo, vo, c, lo, sz
-    keep = u != v
-    u, v = u[keep], v[keep]
+    n_edges = min(int(n_edges), n * (n - 1) // 2)
+
+    def draw(count, frac_in):
+        e_in = int(count * frac_in)
+        e_out = count - e_in
+        c = torch.randint(n_clusters, (e_in,), generator=gen, device=dev)
+        lo = bounds[c]
+        sz = (bounds[c + 1] - lo).double()
+        u = lo + (torch.rand(e_in, generator=gen, device=dev, dtype=torch.float64).pow(skew) * sz).long()
+        v = lo + (torch.rand(e_in, generator=gen, device=dev, dtype=torch.float64).pow(skew) * sz).long()
+        u = torch.cat([u, torch.randint(n, (e_out,), generator=gen, device=dev)]).clamp_(max=n - 1)
+        v = torch.cat([v, torch.randint(n, (e_out,), generator=gen, device=dev)]).clamp_(max=n - 1)
+        keep = u != v
+        u, v = u[keep], v[keep]
+        return torch.minimum(u, v) * n + torch.maximum(u, v)      # undirected key, smaller end first
+
+    und = torch.unique(draw(n_edges, frac_in_cluster))
+    for it in range(40):
+        deficit = n_edges - und.numel()
+        if deficit <= 0:
+            break
+        extra = draw(int(deficit * 1.2) + 16, frac_in_cluster if it < 2 else 0.0)
+        und = torch.unique(torch.cat([und, extra]))
+    if und.numel() > n_edges:                                       # thin the surplus at random
+        keep = torch.randperm(und.numel(), generator=gen, device=dev)[:n_edges]
+        und = und[keep.sort().values]
+    u = torch.div(und, n, rounding_mode="floor")
+    v = und - u * n
+    del und
     diag = torch.arange(n, device=dev, dtype=torch.int64)
     keys = torch.cat([u * n + v, v * n + u, diag * n + diag])
-    del u, v, keep
-    keys = torch.unique(keys)  # sorted, duplicates dropped
+    del u, v
+    keys = torch.sort(keys).values
     rows = torch.div(keys, n, rounding_mode="floor")
     cols = (keys - rows * n).to(torch.int32)
     counts = torch.bincount(rows, minlength=n)
@@ -90,8 +108,12 @@ def shape_batch(workload: str, device, bsize: int | None = None, seed: int = 0):
     bsize = bsize or shape["bsize"]
     n_clusters = 2 * bsize
     n = int(shape["n"] * n_clusters / shape["clusters"])
-    e_in = 0.7 * shape["edges"] * n_clusters / shape["clusters"]
-    e_cross = 4 * 0.3 * shape["edges"] * (bsize / shape["clusters"]) ** 2
+    sz = shape["n"] / shape["clusters"]
+    # in-cluster edges of the full graph: 70 % of all, but a cluster cannot hold more than its pairs (the
+    # skewed draws fill about three quarters of them before the generator turns to uniform edges)
+    e_in_full = min(0.7 * shape["edges"], shape["clusters"] * 0.75 * sz * (sz - 1) / 2)
+    e_in = e_in_full * n_clusters / shape["clusters"]
+    e_cross = 4 * (shape["edges"] - e_in_full) * (bsize / shape["clusters"]) ** 2
     graph, bounds = planted_cluster_graph(n, int(e_in + e_cross), n_clusters, device,
                                           frac_in_cluster=e_in / (e_in + e_cross), seed=seed)
     nodes_of, cluster_ids = cluster_batches(bounds, bsize, seed=seed, return_clusters=True)

@@ -1,7 +1,8 @@
-"""Parity of the LDS-tiled cluster product (spmm_tiled) against the CPU oracle, on fixtures that
+"""Parity of the windowed (LDS-tiled) cluster product (spmm_win) against the CPU oracle, on fixtures that
 provably reach it: every test asserts that the batch carries a tiling and that the tiling holds the
-row classes the kernel treats differently (second window onwards, 17-32 / 33-64 / 65-128 / >128
-in-window entries, 1 / 2 / more than 2 entries outside the window, padding descriptors).
+row classes the kernel treats differently (second window onwards; 17-32 / 33-64 / 65-128 in-window
+entries: one or two chunks of a four-row slot; > 128 and > 256: whole-wave rows with one or more chunks;
+1, 2, 5-16, > 16 entries outside the window, also on whole-wave rows; padding descriptors).
 
 Reference semantics: affinity src/SpectralTrainer.py:284-293, loss :130-137, on a multi-cluster batch
 as src/utils.py:76-90 concatenates it.
@@ -62,6 +63,12 @@ def windowed_pattern(rng, sizes, cross_per_row=0.3, hubs=6, hub_out=5, dense_tai
     hv = rng.integers(0, m, hubs * hub_out)
     r = np.concatenate([r, cu, hu])
     c_ = np.concatenate([c_, cv, hv])
+    if big_hubs:   # two rows linked to most of their (largest) cluster: more than 256 in-window entries
+        c = int(np.argmax(sizes))
+        for i in range(2):
+            nb = rng.choice(sizes[c], size=int(0.8 * sizes[c]), replace=False)
+            r = np.concatenate([r, np.full(len(nb), start[c] + 3 + i)])
+            c_ = np.concatenate([c_, start[c] + nb])
     if big_hubs:   # the rows with the most in-cluster entries also get many entries all over the batch
         deg = np.bincount(r, minlength=m)
         top = np.argsort(-deg)[:big_hubs]
@@ -96,9 +103,10 @@ def tiling_census(b, k, training):
         "windows": len(b._windows), "max_w0": max(a for a, _ in b._windows),
         "len_17_32": int(((inwin >= 17) & (inwin <= 32)).sum()), "len_33_64": int(((inwin >= 33) & (inwin <= 64)).sum()),
         "len_65_128": int(((inwin >= 65) & (inwin <= 128)).sum()), "len_gt128": int((inwin > 128).sum()),
+        "len_gt256": int((inwin > 256).sum()),
         "out1": int((n_out == 1).sum()), "out2": int((n_out == 2).sum()), "out_5_16": int(((n_out > 4) & (n_out <= 16)).sum()),
-        "out_gt16": int((n_out > 16).sum()), "long_with_out": int(((inwin > 64) & (n_out > 0)).sum()),
-        "long_out_gt64": int(((inwin > 64) & (n_out > 64)).sum()),
+        "out_gt16": int((n_out > 16).sum()), "long_with_out": int(((inwin > 128) & (n_out > 0)).sum()),
+        "long_out_gt64": int(((inwin > 128) & (n_out > 64)).sum()),
         "before": int(((lo - p0) > 0).sum()), "after": int(((p1 - hi) > 0).sum()),
         "pad_desc": int((desc[:, 1] == desc[:, 0]).sum()),
         "slabs": int(desc[:, 4].max()) + 1, "ndesc": t.ndesc, "tile_rows": t.rows, "vec": t.vec, "kp": t.kp,
@@ -136,7 +144,7 @@ def test_tiled_lap_matches_oracle_all_row_classes(dev, big_fixture, flavour, k, 
     cen = tiling_census(b, k, True)
     assert cen["vec"] == vec and cen["kp"] >= k and cen["kp"] - k < 8 * vec
     assert cen["windows"] >= 5 and cen["max_w0"] > 0
-    for key in ("len_17_32", "len_33_64", "len_65_128", "len_gt128", "out1", "out2", "out_5_16", "out_gt16",
+    for key in ("len_17_32", "len_33_64", "len_65_128", "len_gt128", "len_gt256", "out1", "out2", "out_5_16", "out_gt16",
                 "long_with_out", "long_out_gt64", "before", "after", "pad_desc"):
         assert cen[key] > 0, (key, cen)
     Yd = torch.tensor(Y, device=dev)
