@@ -121,3 +121,80 @@ def shape_batch(workload: str, device, bsize: int | None = None, seed: int = 0):
     coords, values, shp, _ = graph.subblock(nodes_of[0], mode=(0 if lam == -1 else 2), binarize=False, diag_lambda=lam)
     csz = np.diff(bounds.cpu().numpy())[cluster_ids[0]]
     return ClusterBatch.from_device_coo(shp[0], coords, values, cluster_sizes=csz), shape["k"]
+
+
+def rmat_graph(n: int, n_edges: int, device, a: float = 0.57, b: float = 0.19, c: float = 0.19, seed: int = 0,
+               chunk: int = 1 << 26):
+    """R-MAT graph (quadrant probabilities a, b, c, 1 - a - b - c) on n nodes with EXACTLY n_edges distinct
+    undirected edges, as symmetric CSR pattern with unit diagonal: (rowptr int64[n+1], colidx int32),
+    columns sorted inside a row.  n need not be a power of two: ids are drawn on the next power of two
+    and draws with an end >= n are dropped.  Repeated edges are drawn again."""
+    dev = torch.device(device)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    scale = max(1, int(np.ceil(np.log2(n))))
+    n_edges = min(int(n_edges), n * (n - 1) // 2)
+
+    def draw(count):
+        out = []
+        for lo in range(0, count, chunk):
+            e = min(chunk, count - lo)
+            u = torch.zeros(e, dtype=torch.int64, device=dev)
+            v = torch.zeros(e, dtype=torch.int64, device=dev)
+            for _ in range(scale):
+                r = torch.rand(e, generator=gen, device=dev)
+                u = (u << 1) | (r >= a + b).to(torch.int64)                                   # quadrants c, d: lower half
+                v = (v << 1) | (((r >= a) & (r < a + b)) | (r >= a + b + c)).to(torch.int64)  # quadrants b, d: right half
+            keep = (u != v) & (u < n) & (v < n)
+            u, v = u[keep], v[keep]
+            out.append(torch.unique(torch.minimum(u, v) * n + torch.maximum(u, v)))
+        return torch.unique(torch.cat(out)) if len(out) > 1 else out[0]
+
+    und = draw(n_edges)
+    for _ in range(60):
+        deficit = n_edges - und.numel()
+        if deficit <= 0:
+            break
+        und = torch.unique(torch.cat([und, draw(int(deficit * 1.5) + 1024)]))
+    if und.numel() > n_edges:
+        keep = torch.randperm(und.numel(), generator=gen, device=dev)[:n_edges]
+        und = und[keep.sort().values]
+    u = torch.div(und, n, rounding_mode="floor")
+    v = und - u * n
+    del und
+    return csr_pattern(n, u, v)
+
+
+def csr_pattern(n: int, u: torch.Tensor, v: torch.Tensor):
+    """Symmetric CSR pattern with unit diagonal of the undirected edges (u, v): (rowptr, colidx)."""
+    dev = u.device
+    diag = torch.arange(n, device=dev, dtype=torch.int64)
+    keys = torch.sort(torch.cat([u * n + v, v * n + u, diag * n + diag])).values
+    rows = torch.div(keys, n, rounding_mode="floor")
+    cols = (keys - rows * n).to(torch.int32)
+    del keys
+    counts = torch.bincount(rows, minlength=n)
+    del rows
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    rowptr[1:] = torch.cumsum(counts, 0)
+    return rowptr, cols.contiguous()
+
+
+def degree_order(rowptr: torch.Tensor, colidx: torch.Tensor):
+    """Relabel the nodes by decreasing degree (ties by old id): the rows every other row gathers most often
+    become one contiguous, cache-resident block.  Returns (rowptr, colidx, perm) of P A P^T with
+    perm[new] = old, columns sorted inside a row."""
+    n = rowptr.numel() - 1
+    deg = rowptr[1:] - rowptr[:-1]
+    perm = torch.sort(deg, descending=True, stable=True).indices          # new -> old
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(n, device=perm.device)
+    rows = torch.repeat_interleave(torch.arange(n, device=perm.device), deg)
+    keys = torch.sort(inv[rows] * n + inv[colidx.long()]).values
+    del rows
+    nrows = torch.div(keys, n, rounding_mode="floor")
+    ncols = (keys - nrows * n).to(torch.int32)
+    del keys
+    nptr = torch.zeros(n + 1, dtype=torch.int64, device=perm.device)
+    nptr[1:] = torch.cumsum(torch.bincount(nrows, minlength=n), 0)
+    return nptr, ncols.contiguous(), perm

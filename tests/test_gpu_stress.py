@@ -1,0 +1,49 @@
+"""The plain whole-graph product Z = A X (the SpMM roofline stress of BASELINE config 5) at a size SciPy
+checks in a second: a scaled-down R-MAT graph (same quadrant probabilities, power-law degrees, hub rows
+of thousands of entries) in natural order and relabelled by decreasing degree, through the C ABI."""
+import ctypes
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _spmm(lib, n, rowptr, colidx, val, X):
+    Z = torch.empty_like(X)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    rc = lib.sparc_spmm(n, int(colidx.numel()), P(rowptr), P(colidx), P(val), int(X.shape[1]), P(X), None, P(Z), None,
+                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    return Z
+
+
+@pytest.mark.parametrize("width", [64, 128])
+def test_rmat_product_matches_scipy_in_both_orders(width):
+    from sparc_amd import synth
+    from sparc_amd._lib import lib
+    dev = torch.device("cuda:0")
+    n, e = 20000, 400000                      # not a power of two: exercises the rejection of ids >= n
+    rowptr, colidx = synth.rmat_graph(n, e, dev, seed=3)
+    assert int(colidx.numel()) == 2 * e + n   # exactly the named number of edges, plus the unit diagonal
+    deg = (rowptr[1:] - rowptr[:-1]).cpu().numpy()
+    assert deg.max() > 50 * np.median(deg)    # power-law: hub rows far above the typical degree
+    val = torch.rand(colidx.numel(), device=dev) + 0.5
+    X = torch.randn(n, width, device=dev)
+    A = sp.csr_matrix((val.cpu().numpy().astype(np.float64), colidx.cpu().numpy(), rowptr.cpu().numpy()), shape=(n, n))
+    ref = A @ X.cpu().numpy().astype(np.float64)
+    Z = _spmm(lib, n, rowptr, colidx, val, X).cpu().numpy()
+    scale = np.maximum(np.abs(ref).max(axis=1, keepdims=True), 1e-3)
+    assert (np.abs(Z - ref) / scale).max() < 1e-5
+    # relabelled by decreasing degree: P A P^T (P X) = P (A X)
+    rp2, ci2, perm = synth.degree_order(rowptr, colidx)
+    d2 = (rp2[1:] - rp2[:-1]).cpu().numpy()
+    assert np.all(np.diff(d2) <= 0) and sorted(d2.tolist()) == sorted(deg.tolist())
+    Ap = A[perm.cpu().numpy()][:, perm.cpu().numpy()].tocsr()
+    Ap.sort_indices()
+    assert np.array_equal(Ap.indptr, rp2.cpu().numpy()) and np.array_equal(Ap.indices, ci2.cpu().numpy())
+    val2 = torch.from_numpy(Ap.data.astype(np.float32)).to(dev)
+    Z2 = _spmm(lib, n, rp2, ci2, val2, X[perm].contiguous()).cpu().numpy()
+    assert (np.abs(Z2 - ref[perm.cpu().numpy()]) / scale[perm.cpu().numpy()]).max() < 1e-5

@@ -1,15 +1,18 @@
 #!/usr/bin/env python3
-"""Whole-graph CSR SpMM (k = 64) in the HBM-bound regime: an R-MAT graph (a, b, c, d = 0.57, 0.19,
-0.19, 0.05; 2^23 nodes, about 500 M stored entries) in natural order, and the cluster-ordered
-Amazon2M-shape planted-cluster graph.  One launch of the row-gather kernel per product
-(sparc_spmm); prints one JSON line per graph with the algorithmic bytes, the kernel time (HIP
-events) and the fraction of the 8 TB/s HBM peak."""
+"""Whole-graph CSR SpMM Z = A X (k = 64, values 1) in the HBM-bound regime: the R-MAT stress graph
+(a, b, c, d = 0.57, 0.19, 0.19, 0.05; 10 M nodes, 500 M stored off-diagonal entries + unit diagonal) in
+natural and in degree order, and the cluster-ordered Amazon2M-shape planted-cluster graph with the row
+kernel and with the windowed kernel.  One launch per product (sparc_spmm); prints one JSON line per case
+with the algorithmic bytes, the kernel time (HIP events on the launch stream) and the fraction of the
+8 TB/s HBM peak.  Cases: python tools/spmm_stress.py [rmat] [rmat-degree] [amazon2m] [amazon2m-windowed]
+(RMAT_NODES / RMAT_EDGES shrink the R-MAT graph)."""
 import ctypes
 import json
 import os
 import sys
 import time
 
+import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,53 +21,19 @@ from sparc_amd._lib import check, lib  # noqa: E402
 
 dev = torch.device("cuda:0")
 HBM_PEAK_GBS = 8000.0
+P = lambda t: ctypes.c_void_p(t.data_ptr())
 
 
-def rmat_csr(scale: int, n_edges: int, a=0.57, b=0.19, c=0.19, seed=0, chunk=1 << 26):
-    """Symmetrised, deduplicated R-MAT adjacency with unit diagonal as (rowptr int64, colidx int32)."""
-    n = 1 << scale
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(seed)
-    keys = []
-    done = 0
-    while done < n_edges:
-        e = min(chunk, n_edges - done)
-        u = torch.zeros(e, dtype=torch.int64, device=dev)
-        v = torch.zeros(e, dtype=torch.int64, device=dev)
-        for _ in range(scale):
-            r = torch.rand(e, generator=gen, device=dev)
-            ubit = (r >= a + b).to(torch.int64)                      # quadrants c, d: lower half
-            vbit = (((r >= a) & (r < a + b)) | (r >= a + b + c)).to(torch.int64)  # quadrants b, d: right half
-            u = (u << 1) | ubit
-            v = (v << 1) | vbit
-        keep = u != v
-        u, v = u[keep], v[keep]
-        keys.append(torch.unique(torch.cat([u * n + v, v * n + u])))
-        done += e
-        del u, v, keep
-    diag = torch.arange(n, device=dev, dtype=torch.int64)
-    keys.append(diag * n + diag)
-    keys = torch.unique(torch.cat(keys))
-    rows = torch.div(keys, n, rounding_mode="floor")
-    cols = (keys - rows * n).to(torch.int32)
-    del keys
-    counts = torch.bincount(rows, minlength=n)
-    del rows
-    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
-    rowptr[1:] = torch.cumsum(counts, 0)
-    return n, rowptr, cols.contiguous()
-
-
-def run(name, n, rowptr, colidx, width=64, reps=5):
+def run(name, n, rowptr, colidx, width=64, reps=5, tiling=None, kernel="spmm_rows"):
     nnz = int(colidx.numel())
     val = torch.ones(nnz, dtype=torch.float32, device=dev)
     X = torch.randn(n, width, device=dev)
     Z = torch.empty_like(X)
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    P = lambda t: ctypes.c_void_p(t.data_ptr())
 
     def launch():
-        check(lib.sparc_spmm(n, nnz, P(rowptr), P(colidx), P(val), width, P(X), None, P(Z), None, 0, 0, 0, stream), "sparc_spmm")
+        check(lib.sparc_spmm(n, nnz, P(rowptr), P(colidx), P(val), width, P(X), None, P(Z),
+                             ctypes.byref(tiling) if tiling is not None else None, stream), "sparc_spmm")
 
     launch()
     torch.cuda.synchronize()
@@ -85,27 +54,55 @@ def run(name, n, rowptr, colidx, width=64, reps=5):
         times.append(ev0.elapsed_time(ev1))
     ms = sorted(times)[len(times) // 2]
     alg = nnz * 8 + (n + 1) * 8 + 2 * n * width * 4
-    out = {"graph": name, "nodes": n, "stored_entries": nnz, "width": width, "kernel": "spmm_rows", "ms": ms,
+    out = {"graph": name, "nodes": n, "stored_entries": nnz, "width": width, "kernel": kernel, "ms": ms,
            "algorithmic_bytes": alg, "achieved_GBps": alg / ms / 1e6, "frac_of_hbm_peak": alg / ms / 1e6 / HBM_PEAK_GBS,
+           "gathered_row_GBps": nnz * width * 4 / ms / 1e6, "GFLOPs": 2.0 * nnz * width / ms / 1e6,
            "max_rel_err_sampled_rows": worst}
     print(json.dumps(out), flush=True)
     return out
 
 
 def main():
-    which = sys.argv[1:] or ["amazon2m", "rmat"]
-    if "amazon2m" in which:
+    which = sys.argv[1:] or ["rmat", "rmat-degree", "amazon2m", "amazon2m-windowed"]
+    if "rmat" in which or "rmat-degree" in which:
+        n = int(os.environ.get("RMAT_NODES", 10_000_000))
+        e = int(os.environ.get("RMAT_EDGES", 250_000_000))
         t0 = time.perf_counter()
-        g, _ = synth.planted_cluster_graph(2449029, 61859140, 5000, dev, seed=0)
-        print(f"[stress] amazon2m-shape graph built in {time.perf_counter() - t0:.1f}s", file=sys.stderr, flush=True)
-        run("amazon2m-shape, cluster-ordered", g.n, g.indptr, g.indices)
-        del g
+        rowptr, colidx = synth.rmat_graph(n, e, dev)
+        torch.cuda.synchronize()
+        print(f"[stress] R-MAT graph ({n} nodes, {e} undirected edges) built in {time.perf_counter() - t0:.1f}s", file=sys.stderr, flush=True)
+        if "rmat" in which:
+            run("R-MAT 10M / 500M, natural order", n, rowptr, colidx)
+        if "rmat-degree" in which:
+            t0 = time.perf_counter()
+            rp2, ci2, _ = synth.degree_order(rowptr, colidx)
+            torch.cuda.synchronize()
+            print(f"[stress] degree ordering in {time.perf_counter() - t0:.1f}s", file=sys.stderr, flush=True)
+            del rowptr, colidx
+            run("R-MAT 10M / 500M, nodes relabelled by decreasing degree", n, rp2, ci2)
+            del rp2, ci2
         torch.cuda.empty_cache()
-    if "rmat" in which:
+    if "amazon2m" in which or "amazon2m-windowed" in which:
         t0 = time.perf_counter()
-        n, rowptr, colidx = rmat_csr(23, int(os.environ.get("RMAT_EDGES", 330_000_000)))
-        print(f"[stress] R-MAT graph built in {time.perf_counter() - t0:.1f}s", file=sys.stderr, flush=True)
-        run("R-MAT scale 23, natural order", n, rowptr, colidx)
+        g, bounds = synth.planted_cluster_graph(2449029, 61859140, 5000, dev, seed=0)
+        print(f"[stress] amazon2m-shape graph built in {time.perf_counter() - t0:.1f}s", file=sys.stderr, flush=True)
+        if "amazon2m" in which:
+            run("amazon2m-shape, cluster-ordered", g.n, g.indptr, g.indices)
+        if "amazon2m-windowed" in which:
+            from sparc_amd.graph import ClusterBatch, plan_windows
+            b = ClusterBatch()                       # the whole graph as one batch, its clusters as windows
+            b.m, b.nnz, b.device = g.n, int(g.indices.numel()), dev
+            b.rowptr, b.colidx = g.indptr, g.indices
+            b.val = torch.ones(b.nnz, dtype=torch.float32, device=dev)
+            b.valT = None
+            b._windows = plan_windows(g.n, np.diff(bounds.cpu().numpy()))
+            b._tiles, b._window_ranges = {}, None
+            t0 = time.perf_counter()
+            t = b._plan(4, 64, 1, False, 1024, 256)
+            torch.cuda.synchronize()
+            print(f"[stress] tiling in {time.perf_counter() - t0:.1f}s: {t.ndesc if t else None} workgroups", file=sys.stderr, flush=True)
+            if t is not None:
+                run("amazon2m-shape, cluster-ordered", g.n, g.indptr, g.indices, tiling=t, kernel="spmm_win<vec 4, single>")
 
 
 if __name__ == "__main__":
