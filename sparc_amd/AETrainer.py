@@ -116,9 +116,11 @@ class AETrainer:
         self.ae_net.eval()
         total = torch.zeros((), dtype=torch.float64, device=self.device)
         cached = getattr(self, "_val_dev", None)
+        if cached is not None and valid_loader is not self.val_features_batches:
+            cached = None   # the device copies belong to the batches given to train(), not to this argument
         with torch.no_grad():
             for pid in range(len(valid_loader)):
-                x = cached[pid] if cached is not None else self._dev(self.val_features_batches[pid])
+                x = cached[pid] if cached is not None else self._dev(valid_loader[pid])
                 total += self.criterion(self.ae_net(x), x)
         return float(total) / len(valid_loader)
 

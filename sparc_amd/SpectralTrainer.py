@@ -144,6 +144,7 @@ class SpectralTrainer:
         self.idx_parts, self.val_features_batches, self.val_support_batches, self.y_val_batches, self.val_mask_batches = val
         self.idx_parts = list(range(len(self.parts)))
         self.counter = 0
+        OrthWeights.check_and_reset(self.device)   # failures of earlier, unrelated calls do not belong to this run
         self.criterion = SpectralNetLoss()
         self.spectral_net = SpectralNetModel(self.architecture, input_dim=self.features_batches[0].shape[1],
                                              device=self.device, orth_mode=self.orth_mode).to(self.device)
@@ -190,7 +191,7 @@ class SpectralTrainer:
                     W = self._get_valid_affinity_matrix(vsup[pid], vfeats[pid])
                     valid_loss += self.criterion(W, Y, is_normalized=True)
             train_loss, valid_loss = float(train_loss), float(valid_loss)  # the epoch's only host sync
-            if OrthWeights.last_info is not None and int(OrthWeights.last_info) != 0:
+            if OrthWeights.check_and_reset(self.device) != 0:   # any step of the epoch, not only the last
                 raise torch.linalg.LinAlgError("orthonormalisation: the batch's Gram matrix is not positive definite "
                                                "(the reference's torch.inverse(R) fails on the same input)")
 

@@ -116,6 +116,17 @@ def dgrad_narrow_relu(g: torch.Tensor, W: torch.Tensor, hprev: torch.Tensor):
     return dx, db
 
 
+# Called by SpectralMLP.backward as soon as a layer's weight and bias gradient exist: hook(layer, dW, db) returns the
+# pair to hand to autograd (a data-parallel trainer returns views into a bucket whose all-reduce it has just
+# started, so the collective overlaps the backward products of the layers below).  None: no hook.
+GRAD_READY_HOOK = None
+
+
+def _layer_done(grads, l):
+    if GRAD_READY_HOOK is not None and grads[2 * l] is not None and grads[2 * l + 1] is not None:
+        grads[2 * l], grads[2 * l + 1] = GRAD_READY_HOOK(l, grads[2 * l], grads[2 * l + 1])
+
+
 class SpectralMLP(torch.autograd.Function):
     """The whole SpectralNet MLP (src/SpectralTrainer.py:28-39, :96-97): Linear+ReLU layers and a final
     Linear+Tanh, forward and backward written out so that neighbouring steps share a pass:
@@ -149,6 +160,7 @@ class SpectralMLP(torch.autograd.Function):
         gp, db = act_bwd_bias(_f32c(gy), y, ACT_TANH)
         grads[2 * (L - 1)] = _wgrad(gp, acts[L - 1], Ws[L - 1])
         grads[2 * (L - 1) + 1] = db
+        _layer_done(grads, L - 1)
         gx = None
         if L == 1:
             gx = gp.mm(Ws[0]) if need_x else None
@@ -169,10 +181,12 @@ class SpectralMLP(torch.autograd.Function):
                         and xin.dtype == torch.float32 and pending.data_ptr() % 16 == 0):
                     dWt, db = first_layer_bwd(xin, pending, hout)
                     grads[0], grads[1] = dWt, db
+                    _layer_done(grads, 0)
                     return (None, *grads)
                 gp, db = act_bwd_bias(pending, hout, ACT_RELU)
             grads[2 * l] = _wgrad(gp, acts[l], Ws[l])
             grads[2 * l + 1] = db
+            _layer_done(grads, l)
             if l > 0:
                 pending = gp.mm(Ws[l])
             elif need_x:
@@ -260,7 +274,20 @@ class SplitRows(torch.autograd.Function):
 class OrthWeights(torch.autograd.Function):
     """Yt [m, k] -> orthonormalisation weights [k, k]  (src/SpectralTrainer.py:42-70)."""
 
-    last_info = None
+    last_info = None   # device int of the latest call
+    worst_info = {}    # per device: running maximum over all calls since the last check (a device int)
+
+    @classmethod
+    def check_and_reset(cls, device):
+        """Largest failure code since the previous check on this device (one host sync), then cleared.
+        Non-zero: some call met a Gram matrix that is not positive definite."""
+        key = torch.device(device).index or 0
+        t = cls.worst_info.get(key)
+        if t is None:
+            return 0
+        code = int(t)
+        t.zero_()
+        return code
 
     @staticmethod
     def forward(ctx, Yt, top_idx, mode):
@@ -286,6 +313,10 @@ class OrthWeights(torch.autograd.Function):
         ctx.save_for_backward(Y, saved)
         ctx.mode = int(mode)
         OrthWeights.last_info = info  # device int; non-zero = Gram matrix not positive definite (checked lazily)
+        key = dev.index or 0
+        if key not in OrthWeights.worst_info:
+            OrthWeights.worst_info[key] = torch.zeros(1, dtype=torch.int32, device=dev)
+        torch.maximum(OrthWeights.worst_info[key], info, out=OrthWeights.worst_info[key])   # no step goes unnoticed
         return Wo
 
     @staticmethod

@@ -68,24 +68,67 @@ def all_reduce_mean_gradients(params: Sequence[torch.nn.Parameter], group=None) 
     return flat
 
 
+class LayerwiseReducer:
+    """Gradient all-reduce that starts while the backward is still running: every MLP layer's weight and bias
+    gradient are packed into one small bucket the moment the backward has produced them and the bucket's
+    all-reduce is launched asynchronously (RCCL runs it on its own stream), so it overlaps the backward
+    products of the layers below; finish() waits for all buckets and turns the sums into means.  The
+    gradients handed back to autograd are views into the buckets."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.pending = []
+
+    def on_layer(self, layer: int, dW: torch.Tensor, db: torch.Tensor):
+        flat = torch.cat([dW.reshape(-1), db.reshape(-1)])
+        if _staged(flat, self.group):          # gloo rehearsal on a GPU: through the host, synchronously
+            all_reduce_sum(flat, self.group)
+            work = None
+        else:
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.pending.append((work, flat))
+        n = dW.numel()
+        return flat[:n].view_as(dW), flat[n:].view_as(db)
+
+    def finish(self) -> int:
+        """Wait for every bucket and average; returns the number of buckets reduced."""
+        done = len(self.pending)
+        for work, flat in self.pending:
+            if work is not None:
+                work.wait()
+            flat.div_(self.world)
+        self.pending = []
+        return done
+
+
 class ShardedSpectralTrainer:
-    """Data-parallel SpectralNet steps over this rank's shard of cluster batches."""
+    """Data-parallel SpectralNet steps over this rank's shard of cluster batches.  net / criterion can be
+    injected (anything with forward_pair(x2, x1, top_idx=) and __call__(batch, Y, is_normalized=)); by
+    default they are the MI355X SpectralNetModel and SpectralNetLoss."""
 
     def __init__(self, architecture: dict, input_dim: int, device, lr: float = 1e-3, orth_mode: str = "reference",
-                 group=None, seed: Optional[int] = 0):
-        from .SpectralTrainer import SpectralNetLoss, SpectralNetModel
+                 group=None, seed: Optional[int] = 0, net=None, criterion=None, fused_adam: bool = True):
         self.device = torch.device(device)
         if seed is not None:
             torch.manual_seed(seed)  # identical initial weights on every rank
-        self.net = SpectralNetModel(architecture, input_dim, self.device, orth_mode=orth_mode).to(self.device)
+        if net is None:
+            from .SpectralTrainer import SpectralNetModel
+            net = SpectralNetModel(architecture, input_dim, self.device, orth_mode=orth_mode).to(self.device)
+        if criterion is None:
+            from .SpectralTrainer import SpectralNetLoss
+            criterion = SpectralNetLoss()
+        self.net = net
         self.k = architecture["output_dim"]
         self.group = group
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        if self.distributed:
             for p in self.net.parameters():
                 broadcast(p.data, 0, group)
         self.params = list(self.net.parameters())
-        self.optimizer = torch.optim.Adam(self.net.parameters(), lr=lr, fused=True)
-        self.criterion = SpectralNetLoss()
+        self.optimizer = torch.optim.Adam(self.net.parameters(), lr=lr, fused=fused_adam)
+        self.criterion = criterion
+        self.reducer = LayerwiseReducer(group) if self.distributed else None
         self.features = []
         self.batches = []
 
@@ -96,14 +139,23 @@ class ShardedSpectralTrainer:
 
     def step(self, pid: int, pid_2: int, top_idx=None) -> torch.Tensor:
         """Orthogonality step on local batch pid_2, gradient step on local batch pid
-        (src/SpectralTrainer.py:216-238), gradient averaged over the ranks before Adam."""
+        (src/SpectralTrainer.py:216-238), gradient averaged over the ranks before Adam: layer by layer
+        while the backward runs when the MLP reports its layers (ops.GRAD_READY_HOOK), in one bucket after
+        the backward otherwise."""
+        from . import ops
         net = self.net
         net.train()
         self.optimizer.zero_grad(set_to_none=True)   # autograd hands its gradients over as they are: no accumulation
         Y = net.forward_pair(self.features[pid_2], self.features[pid], top_idx=top_idx)
         loss = self.criterion(self.batches[pid], Y, is_normalized=True)
-        loss.backward()
-        all_reduce_mean_gradients(self.params, self.group)   # one bucket, one collective (nothing on a single rank)
+        if self.distributed:
+            ops.GRAD_READY_HOOK = self.reducer.on_layer
+        try:
+            loss.backward()
+        finally:
+            ops.GRAD_READY_HOOK = None
+        if self.distributed and self.reducer.finish() == 0:
+            all_reduce_mean_gradients(self.params, self.group)   # no layer reported: one bucket, one collective
         self.optimizer.step()
         return loss.detach()
 
@@ -115,6 +167,6 @@ class ShardedSpectralTrainer:
         for x, b in zip(features, batches):
             Y = self.net(x.to(self.device), should_update_orth_weights=False)
             total += self.criterion(b, Y, is_normalized=True)
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        if self.distributed:
             all_reduce_sum(total, self.group)
         return total

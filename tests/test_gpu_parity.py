@@ -731,3 +731,50 @@ def test_facade_fit_predict_with_autoencoder(dev, golden, tmp_path, monkeypatch,
     save_results(str(tmp_path / "sparc_results" / "facade"), Y, X, np.zeros(len(X), int), np.ones(len(X), bool),
                  np.ones(len(X), bool), np.ones(len(X), bool), E)
     assert np.allclose(np.load(tmp_path / "sparc_results" / "facade" / "embeddings.npy"), Y / np.sqrt(len(X)))
+
+
+# ---------------------------------------------------------------- real graph: Cora through the reference's loader
+def test_cora_batch_matches_reference(dev, golden):
+    """BASELINE config 1's graph (m = 2437, 11 041 stored entries, off-diagonal weight 2, k = 64): support built
+    on the device bit-exact, affinity sums, orthonormalisation weights, embedding, both loss branches and the
+    gradient against the imported reference (tools/gen_golden_cora.py)."""
+    from sparc_amd import utils as U
+    from sparc_amd.SpectralTrainer import SpectralNetLoss, SpectralNetModel
+    from sparc_amd.graph import ClusterBatch
+    g = golden("g7_cora.npz")
+    n = int(g["num_data"])
+    train_adj = sp.csr_matrix((g["train_data_values"], g["train_indices"], g["train_indptr"]), shape=(n, n))
+    graph = U.DeviceGraph.from_scipy(train_adj, dev)
+    coords, values, shape, _ = graph.subblock(g["train_part"].astype(np.int32), mode=0, binarize=False)
+    r0, c0, v0, sh0 = O.canonical_support(sup(g, "sup_"))
+    assert tuple(shape) == sh0 and np.array_equal(coords.cpu().numpy()[:, 0], r0) and np.array_equal(coords.cpu().numpy()[:, 1], c0)
+    assert np.array_equal(values.cpu().numpy(), v0)
+    full = sp.csr_matrix((g["full_data"], g["full_indices"], g["full_indptr"]), shape=(n, n))
+    vcoords, vvalues, vshape, _ = U.DeviceGraph.from_scipy(full, dev).subblock(np.arange(n, dtype=np.int32), mode=1, binarize=True)
+    r1, c1, v1, _ = O.canonical_support(sup(g, "val_"))
+    assert np.array_equal(vcoords.cpu().numpy()[:, 0], r1) and np.array_equal(vcoords.cpu().numpy()[:, 1], c1)
+    assert np.array_equal(vvalues.cpu().numpy(), v1)
+
+    b = ClusterBatch.from_device_coo(shape[0], coords, values)
+    assert rel(b.d.cpu().numpy(), g["W_rowsum"]) < TOL and rel(b.cw.cpu().numpy(), g["W_colsum"]) < TOL
+    m, k = shape[0], 64
+    rng = np.random.default_rng(7)
+    rng.integers(0, m, size=(256, 2))
+    Yt = torch.tensor(rng.standard_normal((m, k)).astype(np.float32), device=dev)
+    model = SpectralNetModel({"n_layers": 2, "h": 4, "output_dim": k}, 3, dev)
+    Wo = model._make_orthonorm_weights(Yt)
+    assert rel(Wo.cpu().numpy(), g["orth"]) < TOL
+    Y = (Yt @ torch.tensor(g["orth"], device=dev)).requires_grad_(True)
+    assert rel(Y.detach().cpu().numpy()[g["grad_rows"]], g["Y_rows"]) < TOL
+    for use_tiles in (True, False):          # one window of 512 rows at a time, or the row kernel
+        ClusterBatch.use_tiles = use_tiles
+        try:
+            Y.grad = None
+            loss = SpectralNetLoss()(b, Y, is_normalized=True)
+            loss.backward()
+            assert rel(loss.item(), g["loss"]) < TOL
+            assert rel(Y.grad.cpu().numpy()[g["grad_rows"]], g["gradY_rows"]) < TOL
+            assert rel(Y.grad.norm(dim=1).cpu().numpy(), g["gradY_rownorm"]) < TOL
+            assert rel(SpectralNetLoss()(b, Y.detach(), is_normalized=False).item(), g["loss_plain"]) < TOL
+        finally:
+            ClusterBatch.use_tiles = True

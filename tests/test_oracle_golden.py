@@ -222,3 +222,52 @@ def test_token_lists_oracle_matches_reference(golden):
     t = O.spectral_token_lists(g["encoding"], g["features"], int(g["K"]))
     assert t.shape == g["tokens"].shape and t.dtype == np.float32
     assert np.abs(t - g["tokens"]).max() < 1e-6
+
+
+# ---------------------------------------------------------------- real graph: Cora through the reference's loader
+def _cora_yt(m, k=64):
+    """The pre-orthonormalisation output tools/gen_golden_cora.py drew (same generator, same call order)."""
+    rng = np.random.default_rng(7)
+    rng.integers(0, m, size=(256, 2))
+    return rng.standard_normal((m, k)).astype(np.float32)
+
+
+def test_cora_plumbing_counts(golden):
+    """The facts of the shipped Cora graph as the reference's loader sees it (src/utils.py:140-255): the
+    split, the stored-entry counts, off-diagonal weight 2 (both link directions of the multigraph add up)."""
+    g = golden("g7_cora.npz")
+    assert (int(g["num_data"]), int(g["n_train"]), int(g["n_val"]), int(g["n_test"])) == (2708, 2437, 189, 82)
+    assert int(g["train_adj_nnz"]) == 11312 and int(g["full_adj_nnz"]) == 13264
+    assert g["offdiag_values"].tolist() == [2.0] and g["diag_values"].tolist() == [1.0]
+    assert tuple(g["sup_shape"]) == (2437, 2437) and len(g["sup_values"]) == 11041
+    assert np.allclose(g["val_rowsums"], 1.0, atol=1e-12)       # validation supports are row-normalised
+
+
+def test_cora_oracle_support_and_loss(golden):
+    g = golden("g7_cora.npz")
+    n = int(g["num_data"])
+    train_adj = sp.csr_matrix((g["train_data_values"], g["train_indices"], g["train_indptr"]), shape=(n, n))
+    parts = [g["train_part"].copy()]
+    nodes, sups = O.multicluster_batches(train_adj, parts, 1, 100000, -1, shuffle_rng=np.random.RandomState(0))
+    ours, ref = O.canonical_support(sups[0]), O.canonical_support(sup(g, "sup_"))
+    for a, b in zip(ours[:3], ref[:3]):
+        assert np.array_equal(a, b)
+    full = sp.csr_matrix((g["full_data"], g["full_indices"], g["full_indptr"]), shape=(n, n))
+    part_adj, vparts = O.intra_part_adjacency(full, np.arange(n), np.zeros(n, int), 1)
+    vs = O.partition_batches(part_adj, [np.asarray(p) for p in vparts], -1)[0]
+    ours, ref = O.canonical_support(vs), O.canonical_support(sup(g, "val_"))
+    assert np.array_equal(ours[0], ref[0]) and np.array_equal(ours[1], ref[1]) and np.array_equal(ours[2], ref[2])
+    # affinity, orthonormalisation, loss and gradient at m = 2437, k = 64
+    s = sup(g, "sup_")
+    A, _ = O.csr_from_support(s)
+    prep = O.affinity_prep_operator(A)
+    assert rel(prep["d"], g["W_rowsum"]) < 2e-5 and rel(prep["cw"], g["W_colsum"]) < 2e-5
+    Yt = _cora_yt(A.shape[0])
+    assert abs(Yt.astype(np.float64).sum() - float(g["Yt_sum"])) < 1e-6 * float(g["Yt_abs_sum"])
+    Wo = O.orthonorm_weights_qr(torch.tensor(Yt, dtype=torch.float64)).numpy()
+    assert rel(Wo, g["orth"]) < 1e-4
+    Y = Yt.astype(np.float64) @ g["orth"].astype(np.float64)
+    loss, gY, _, _ = O.lap_forward_operator(A, prep, Y)
+    assert rel(loss, g["loss"]) < 2e-5
+    assert rel(gY[g["grad_rows"]], g["gradY_rows"]) < 1e-4
+    assert rel(np.linalg.norm(gY, axis=1), g["gradY_rownorm"]) < 1e-4
