@@ -468,7 +468,9 @@ def test_train_step_matches_reference_golden(dev, golden):
     assert rel(Y.detach().cpu().numpy()[g["perm1"]], g["Y"]) < TOL      # the reference permuted the batch
     assert rel(loss.item(), g["loss"]) < TOL
     for name, p in net.named_parameters():
-        assert rel(p.grad.cpu().numpy(), g["grad." + name]) < 5e-4, name
+        # observed: <= 1.4e-5, except the output layer's bias (1.8e-4): a sum over the rows of terms that nearly
+        # cancel, which the reference's own float32 summation resolves no better
+        assert rel(p.grad.cpu().numpy(), g["grad." + name]) < (5e-4 if name == "layers.3.0.bias" else 5e-5), name
     opt.step()
     for name, p in net.state_dict().items():
         assert rel(p.cpu().numpy(), g["after." + name]) < TOL, name
@@ -497,7 +499,9 @@ def test_forward_pair_equals_two_forwards(dev, golden):
     assert rel(Y.detach().cpu().numpy()[g["perm1"]], g["Y"]) < TOL
     assert rel(loss.item(), g["loss"]) < TOL
     for name, p in net.named_parameters():
-        assert rel(p.grad.cpu().numpy(), g["grad." + name]) < 5e-4, name
+        # observed: <= 1.4e-5, except the output layer's bias (1.8e-4): a sum over the rows of terms that nearly
+        # cancel, which the reference's own float32 summation resolves no better
+        assert rel(p.grad.cpu().numpy(), g["grad." + name]) < (5e-4 if name == "layers.3.0.bias" else 5e-5), name
 
 
 def test_trainer_end_to_end_matches_reference(dev, golden, tmp_path, monkeypatch, capsys):
@@ -527,10 +531,11 @@ def test_trainer_end_to_end_matches_reference(dev, golden, tmp_path, monkeypatch
         return [float(x) for x in re.findall(r"[-+]?\d+\.\d+", line)]
     for a, b in zip(our_lines, ref_lines):
         na, nb = nums(a), nums(b)
-        assert abs(na[0] - nb[0]) / nb[0] < 2e-3 and abs(na[1] - nb[1]) / nb[1] < 2e-3, (a, b)
+        # observed on an MI355X: 3e-7 (tools/tol_probe.py); the printed losses carry 7 decimals
+        assert abs(na[0] - nb[0]) / nb[0] < 1e-5 and abs(na[1] - nb[1]) / nb[1] < 1e-5, (a, b)
     # initialisation used the same torch RNG stream as the reference
     for name, p in net.state_dict().items():
-        assert rel(p.cpu().numpy(), g["final." + name]) < 2e-2, name
+        assert rel(p.cpu().numpy(), g["final." + name]) < 1e-5, name      # observed: 5e-7 after the six Adam steps
     assert (tmp_path / "weights" / "golden" / "spectralnet_weights.pth").exists()
 
 
@@ -657,11 +662,11 @@ def test_autoencoder_stage_matches_reference(dev, golden, tmp_path, monkeypatch,
     our_lines = [l for l in out.splitlines() if l.startswith("Epoch")]
     assert our_lines == ref_lines                     # losses printed with 4 decimals
     for name, p in ae.state_dict().items():
-        assert rel(p.cpu().numpy(), g["final." + name]) < 1e-3, name
+        assert rel(p.cpu().numpy(), g["final." + name]) < 1e-5, name      # observed: 1.3e-7
     for b in range(3):
-        assert rel(enc[b].cpu().numpy(), g[f"enc{b}"]) < 1e-3
+        assert rel(enc[b].cpu().numpy(), g[f"enc{b}"]) < 1e-5
     for b in range(2):
-        assert rel(enc_val[b].cpu().numpy(), g[f"venc{b}"]) < 1e-3
+        assert rel(enc_val[b].cpu().numpy(), g[f"venc{b}"]) < 1e-5
     assert (tmp_path / "weights" / "golden_ae" / "ae_weights_5.pth").exists()
     # a second trainer finds the checkpoint and loads it instead of training (src/AETrainer.py:88-90)
     ae2 = AETrainer(AE_CFG, dev).train(fb, vb)
@@ -669,7 +674,7 @@ def test_autoencoder_stage_matches_reference(dev, golden, tmp_path, monkeypatch,
         assert n1 == n2 and torch.equal(p1, p2)
     # single-row helper and the module's own forward
     x = fb[0].to(dev)
-    assert rel(tr.embed_single(fb[0]).cpu().numpy(), g["enc0"]) < 1e-3
+    assert rel(tr.embed_single(fb[0]).cpu().numpy(), g["enc0"]) < 1e-5
     rec = ae(x)
     assert rec.shape == x.shape
 
