@@ -193,7 +193,7 @@ def main():
         pt = nodes_of[b]
         coords, values, shp, _ = graph.subblock(pt, mode=(0 if lam == -1 else 2), binarize=False, diag_lambda=lam)
         csz = np.diff(bounds.cpu().numpy())[cluster_ids[b]]
-        cb = ClusterBatch.from_device_coo(shp[0], coords, values, cluster_sizes=csz).warm(k)
+        cb = ClusterBatch.from_device_coo(shp[0], coords, values, cluster_sizes=csz).warm(k, measure=True)
         trainer.add_batch(synth.block_features(pt, bounds, din, 47), cb)
     torch.cuda.synchronize()
     t_prep = time.perf_counter() - t0

@@ -156,10 +156,10 @@ class SpectralTrainer:
         # one-time: features and supports to the device
         feats = [f.to(self.device, dtype=torch.float32) for f in self.features_batches]
         sizes = self._cluster_sizes()
-        sup = [self._get_support_matrix(s, sizes[i] if sizes else None).warm(k)
+        sup = [self._get_support_matrix(s, sizes[i] if sizes else None).warm(k, measure=True)
                for i, s in enumerate(self.support_batches)]
         vfeats = [f.to(self.device, dtype=torch.float32) for f in self.val_features_batches]
-        vsup = [self._get_support_matrix(s).warm(k, training=False) for s in self.val_support_batches]
+        vsup = [self._get_support_matrix(s).warm(k, training=False, measure=True) for s in self.val_support_batches]
 
         min_val_loss = 1000000000
         batches = len(feats)

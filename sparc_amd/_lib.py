@@ -8,7 +8,7 @@ import os
 from ctypes import c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsparc_hip.so")
+LIB_PATH = os.environ.get("SPARC_HIP_LIB") or os.path.join(_HERE, "lib", "libsparc_hip.so")   # SPARC_HIP_LIB: another build of it
 
 ERRORS = {-1: "SPARC_ERR_ARG (bad argument)", -2: "SPARC_ERR_WS (workspace too small or misaligned)",
           -3: "SPARC_ERR_LAUNCH (HIP launch failed)",

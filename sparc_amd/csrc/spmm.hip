@@ -381,53 +381,56 @@ __device__ __forceinline__ void lds_chunk(float (&acc0)[VEC], float (&acc1)[VEC]
 }
 
 // Entries outside the window: the operand rows come from global memory (the slab's rows are 16 VEC floats
-// apart).  Issue and use are separate so that the loads of a slot's first four outside entries travel
-// behind its LDS work.
+// apart), OG at a time (8 with the narrow lanes, 4 with the wide ones: registers).  Issue and use are separate
+// so that the loads of a slot's first outside entries travel behind its LDS work.
+#ifndef SPARC_OUTSIDE_DEPTH2
+#define SPARC_OUTSIDE_DEPTH2 4
+#endif
 template <int VEC>
-struct Outside4 {
-    typename VecOf<VEC>::T x[4];
+struct OutsideG {
+    static constexpr int N = VEC == 2 ? SPARC_OUTSIDE_DEPTH2 : 4;
+    typename VecOf<VEC>::T x[N];
 };
 
-template <int VEC, int U>
-__device__ __forceinline__ Outside4<VEC> outside_issue4(const Chunk& ck, const float* __restrict__ lane_ptr) {
+template <int VEC, int U, int Q = 0>
+__device__ __forceinline__ void outside_issue(OutsideG<VEC>& o, const Chunk& ck, const float* __restrict__ lane_ptr) {
     typedef typename VecOf<VEC>::T V;
-    Outside4<VEC> o;
-    const int r0 = bcast_add<U>(ck.addr, 0), r1 = bcast_add<U + 1>(ck.addr, 0);
-    const int r2 = bcast_add<U + 2>(ck.addr, 0), r3 = bcast_add<U + 3>(ck.addr, 0);
-    o.x[0] = *reinterpret_cast<const V*>(lane_ptr + static_cast<int64_t>(r0) * (16 * VEC));
-    o.x[1] = *reinterpret_cast<const V*>(lane_ptr + static_cast<int64_t>(r1) * (16 * VEC));
-    o.x[2] = *reinterpret_cast<const V*>(lane_ptr + static_cast<int64_t>(r2) * (16 * VEC));
-    o.x[3] = *reinterpret_cast<const V*>(lane_ptr + static_cast<int64_t>(r3) * (16 * VEC));
-    return o;
+    if constexpr (Q < OutsideG<VEC>::N) {
+        const int r = bcast_add<(U + Q) & 15>(ck.addr, 0);
+        o.x[Q] = *reinterpret_cast<const V*>(lane_ptr + static_cast<int64_t>(r) * (16 * VEC));
+        outside_issue<VEC, U, Q + 1>(o, ck, lane_ptr);
+    }
 }
 
-template <int VEC, bool DUAL, int U>
-__device__ __forceinline__ void outside_use4(float (&acc0)[VEC], float (&acc1)[VEC], const Chunk& ck, const Outside4<VEC>& o) {
-    vec_fma<VEC>(acc0, bcast_weight<DUAL, U>(ck.v, ck.vt), o.x[0]);
-    vec_fma<VEC>(acc1, bcast_weight<DUAL, U + 1>(ck.v, ck.vt), o.x[1]);
-    vec_fma<VEC>(acc0, bcast_weight<DUAL, U + 2>(ck.v, ck.vt), o.x[2]);
-    vec_fma<VEC>(acc1, bcast_weight<DUAL, U + 3>(ck.v, ck.vt), o.x[3]);
+template <int VEC, bool DUAL, int U, int Q = 0>
+__device__ __forceinline__ void outside_use(float (&acc0)[VEC], float (&acc1)[VEC], const Chunk& ck, const OutsideG<VEC>& o) {
+    if constexpr (Q < OutsideG<VEC>::N) {
+        vec_fma<VEC>((Q & 1) ? acc1 : acc0, bcast_weight<DUAL, (U + Q) & 15>(ck.v, ck.vt), o.x[Q]);
+        outside_use<VEC, DUAL, U, Q + 1>(acc0, acc1, ck, o);
+    }
 }
 
-template <int VEC, bool DUAL, int U>
-__device__ __forceinline__ void outside_step4(float (&acc0)[VEC], float (&acc1)[VEC], const Chunk& ck,
-                                              const float* __restrict__ lane_ptr) {
-    const Outside4<VEC> o = outside_issue4<VEC, U>(ck, lane_ptr);
-    outside_use4<VEC, DUAL, U>(acc0, acc1, ck, o);
-}
-
-// steps [first, steps) of an outside chunk, four at a time
+// steps [first, steps) of an outside chunk (first: a multiple of the group size), one group of loads at a time
 template <int VEC, bool DUAL>
 __device__ __forceinline__ void outside_chunk(float (&acc0)[VEC], float (&acc1)[VEC], const Chunk& ck, const int first,
                                               const int steps, const float* __restrict__ lane_ptr) {
-    if (first <= 0 && steps > 0) outside_step4<VEC, DUAL, 0>(acc0, acc1, ck, lane_ptr);
-    if (first <= 4 && steps > 4) outside_step4<VEC, DUAL, 4>(acc0, acc1, ck, lane_ptr);
-    if (first <= 8 && steps > 8) outside_step4<VEC, DUAL, 8>(acc0, acc1, ck, lane_ptr);
-    if (steps > 12) outside_step4<VEC, DUAL, 12>(acc0, acc1, ck, lane_ptr);
+    constexpr int N = OutsideG<VEC>::N;
+#define SPARC_O(U)                                               \
+    if (U % N == 0 && first <= U && steps > U) {                 \
+        OutsideG<VEC> o;                                         \
+        outside_issue<VEC, U>(o, ck, lane_ptr);                  \
+        outside_use<VEC, DUAL, U>(acc0, acc1, ck, o);            \
+    }
+    SPARC_O(0) SPARC_O(4) SPARC_O(8) SPARC_O(12)
+#undef SPARC_O
 }
 
-template <int VEC, bool DUAL, int EPI>
+template <int VEC, bool DUAL, int EPI, bool SYM>
 __global__ __launch_bounds__(WIN_MAX_THREADS) void spmm_win(const SpmmArgs a) {
+    // SYM (training pass on a numerically symmetric matrix): valT == val, one weight per entry for both halves
+    constexpr bool TWO = DUAL && !SYM;
+    // the widest variants keep one slot's operands in registers at a time (no request one slot ahead)
+    constexpr bool AHEAD = !(VEC == 4 && (EPI == EPI_LAP_SINGLE || EPI == EPI_LAP_DUAL));
     extern __shared__ float4 tile[];  // [window rows][16 lanes][VEC floats]
     __shared__ int4 info[WIN_MAX_RECORDS];  // the slot records of this workgroup
     typedef typename VecOf<VEC>::T V;
@@ -497,9 +500,9 @@ __global__ __launch_bounds__(WIN_MAX_THREADS) void spmm_win(const SpmmArgs a) {
         int4 ri = make_int4(-1, 0, 0, 0);
         if (slot < nslots) ri = info[slot * 4 + g];
         s.ri = ri;
-        s.c0 = load_entries4<DUAL>(a, static_cast<unsigned>(ri.y) + lane4, lr < (ri.w & 0xffff));
+        s.c0 = load_entries4<TWO>(a, static_cast<unsigned>(ri.y) + lane4, lr < (ri.w & 0xffff));
         s.o0.addr = 0; s.o0.v = 0.f; s.o0.vt = 0.f;
-        if (has_out) s.o0 = load_outside<DUAL>(a, static_cast<unsigned>(ri.z) + lane1, lr < (ri.w >> 16));
+        if (has_out) s.o0 = load_outside<TWO>(a, static_cast<unsigned>(ri.z) + lane1, lr < (ri.w >> 16));
 #pragma unroll
         for (int q = 0; q < VEC; ++q) s.x0[q] = 0.f;
         if (EPI != EPI_STORE) load_vec<VEC>(s.x0, X0s + static_cast<int64_t>(ri.x >= 0 ? ri.x : 0) * RW);
@@ -524,27 +527,27 @@ __global__ __launch_bounds__(WIN_MAX_THREADS) void spmm_win(const SpmmArgs a) {
         float acc[VEC], acc1[VEC];
 #pragma unroll
         for (int q = 0; q < VEC; ++q) acc[q] = acc1[q] = 0.f;
-        Outside4<VEC> o4;
+        OutsideG<VEC> og;
         int osteps = 0;
-        if (has_out) {  // the first four outside operand rows travel behind the LDS work
+        if (has_out) {  // the first outside operand rows travel behind the LDS work
             osteps = __builtin_amdgcn_readfirstlane(ri.w >> 16);
-            if (osteps > 0) o4 = outside_issue4<VEC, 0>(cur.o0, Xs);
+            if (osteps > 0) outside_issue<VEC, 0>(og, cur.o0, Xs);
         }
-        if (groups > 0) lds_chunk<VEC, DUAL>(acc, acc1, cur.c0, min(groups, 16), lane_base);
+        if (groups > 0) lds_chunk<VEC, TWO>(acc, acc1, cur.c0, min(groups, 16), lane_base);
         if (groups > 16) {  // rows of more than 256 in-window entries: the next chunk is requested before this one is used
-            Chunk4 ck = load_entries4<DUAL>(a, static_cast<unsigned>(ri.y) + 256 + lane4, lr + 16 < groups);
+            Chunk4 ck = load_entries4<TWO>(a, static_cast<unsigned>(ri.y) + 256 + lane4, lr + 16 < groups);
             for (int c = 1; c * 16 < groups; ++c) {
-                const Chunk4 cn = load_entries4<DUAL>(a, static_cast<unsigned>(ri.y) + (c + 1) * 256 + lane4, lr + (c + 1) * 16 < groups);
-                lds_chunk<VEC, DUAL>(acc, acc1, ck, min(groups - c * 16, 16), lane_base);
+                const Chunk4 cn = load_entries4<TWO>(a, static_cast<unsigned>(ri.y) + (c + 1) * 256 + lane4, lr + (c + 1) * 16 < groups);
+                lds_chunk<VEC, TWO>(acc, acc1, ck, min(groups - c * 16, 16), lane_base);
                 ck = cn;
             }
         }
         if (osteps > 0) {
-            outside_use4<VEC, DUAL, 0>(acc, acc1, cur.o0, o4);
-            outside_chunk<VEC, DUAL>(acc, acc1, cur.o0, 4, min(osteps, 16), Xs);
+            outside_use<VEC, TWO, 0>(acc, acc1, cur.o0, og);
+            outside_chunk<VEC, TWO>(acc, acc1, cur.o0, OutsideG<VEC>::N, min(osteps, 16), Xs);
             for (int c = 1; c * 16 < osteps; ++c) {
-                const Chunk ck = load_outside<DUAL>(a, static_cast<unsigned>(ri.z) + c * 64 + lane1, lr + c * 16 < osteps);
-                outside_chunk<VEC, DUAL>(acc, acc1, ck, 0, min(osteps - c * 16, 16), Xs);
+                const Chunk ck = load_outside<TWO>(a, static_cast<unsigned>(ri.z) + c * 64 + lane1, lr + c * 16 < osteps);
+                outside_chunk<VEC, TWO>(acc, acc1, ck, 0, min(osteps - c * 16, 16), Xs);
             }
         }
 #pragma unroll
@@ -560,15 +563,22 @@ __global__ __launch_bounds__(WIN_MAX_THREADS) void spmm_win(const SpmmArgs a) {
         row_epilogue<VEC, DUAL, EPI>(a, row, lane, owner, 8, cl, right, pre, lc, acc, outs ? outs + row * RW : nullptr, 0,
                                      wloss);
     };
-    // two slots in turn, so that no register that a load is still writing has to be copied
-    Slot sa, sb;
-    fetch(sa, slot_of(0));
-    for (int round = 0; round * nwaves < nslots; round += 2) {  // wave-uniform
-        fetch(sb, slot_of(round + 1));
-        work(sa, slot_of(round));
-        if ((round + 1) * nwaves >= nslots) break;
-        fetch(sa, slot_of(round + 2));
-        work(sb, slot_of(round + 1));
+    if (AHEAD) {  // two slots in turn, so that no register that a load is still writing has to be copied
+        Slot sa, sb;
+        fetch(sa, slot_of(0));
+        for (int round = 0; round * nwaves < nslots; round += 2) {  // wave-uniform
+            fetch(sb, slot_of(round + 1));
+            work(sa, slot_of(round));
+            if ((round + 1) * nwaves >= nslots) break;
+            fetch(sa, slot_of(round + 2));
+            work(sb, slot_of(round + 1));
+        }
+    } else {
+        Slot sa;
+        for (int round = 0; round * nwaves < nslots; ++round) {  // wave-uniform
+            fetch(sa, slot_of(round));
+            work(sa, slot_of(round));
+        }
     }
 
     if (a.stamps && lane == 0) {  // developer timeline: per wave {start, after the barrier, end, slots}
@@ -726,7 +736,7 @@ int launch_rows(const SpmmArgs& a, hipStream_t stream) {
 long long* g_stamps = nullptr;  // developer timeline buffer (SPARC_DBG & 64), set by sparc_debug_stamps
 
 // Per device and per instantiation: allow the large dynamic LDS allocation.
-template <int VEC, bool DUAL, int EPI>
+template <int VEC, bool DUAL, int EPI, bool SYM>
 int configure_win() {
     static std::mutex mu;
     static bool done[64] = {};
@@ -734,7 +744,7 @@ int configure_win() {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SPARC_ERR_LAUNCH;
     std::lock_guard<std::mutex> lock(mu);
     if (!done[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_win<VEC, DUAL, EPI>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_win<VEC, DUAL, EPI, SYM>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, SPARC_TILE_LDS_BYTES) != hipSuccess)
             return SPARC_ERR_LAUNCH;
         done[dev] = true;
@@ -742,12 +752,12 @@ int configure_win() {
     return SPARC_OK;
 }
 
-template <int VEC, bool DUAL, int EPI>
+template <int VEC, bool DUAL, int EPI, bool SYM = false>
 int launch_win(const SpmmArgs& a, hipStream_t stream) {
     if (a.ndesc <= 0) return SPARC_OK;
     const size_t lds = static_cast<size_t>(a.tile_rows) * 64 * VEC;
     if (lds > SPARC_TILE_LDS_BYTES || a.threads < 64 || a.threads > WIN_MAX_THREADS || a.threads % 64) return SPARC_ERR_ARG;
-    const int rc = configure_win<VEC, DUAL, EPI>();
+    const int rc = configure_win<VEC, DUAL, EPI, SYM>();
     if (rc) return rc;
     SpmmArgs b = a;
     static const int dbg = [] {  // developer switch for kernel ablation timings, read once
@@ -756,7 +766,7 @@ int launch_win(const SpmmArgs& a, hipStream_t stream) {
     }();
     b.dbg = dbg;
     b.stamps = (dbg & 64) && EPI == EPI_ADD_X0 ? g_stamps : nullptr;
-    hipLaunchKernelGGL((spmm_win<VEC, DUAL, EPI>), dim3(static_cast<unsigned>(a.ndesc)), dim3(a.threads), lds, stream, b);
+    hipLaunchKernelGGL((spmm_win<VEC, DUAL, EPI, SYM>), dim3(static_cast<unsigned>(a.ndesc)), dim3(a.threads), lds, stream, b);
     SPARC_CHECK_LAUNCH();
     return SPARC_OK;
 }
@@ -775,7 +785,11 @@ int launch_single(int width, const SpmmArgs& a, hipStream_t s) {
 
 template <int EPI>
 int launch_dual(int kp, const SpmmArgs& a, hipStream_t s) {
-    if (a.desc) return a.vec == 2 ? launch_win<2, true, EPI>(a, s) : launch_win<4, true, EPI>(a, s);
+    if (a.desc) {
+        if (a.s_valT == a.s_val && a.o_valT == a.o_val)   // numerically symmetric matrix: one weight per entry
+            return a.vec == 2 ? launch_win<2, true, EPI, true>(a, s) : launch_win<4, true, EPI, true>(a, s);
+        return a.vec == 2 ? launch_win<2, true, EPI>(a, s) : launch_win<4, true, EPI>(a, s);
+    }
     switch (kp) {
         case 16: return launch_rows<8, true, EPI>(a, s);
         case 32: return launch_rows<16, true, EPI>(a, s);

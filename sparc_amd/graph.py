@@ -20,7 +20,6 @@ TILE_LDS_BYTES = 128 * 1024   # LDS budget of one window (rows * 64 * vec bytes)
 TILE_MAX_ROWS = 512           # rows of one window
 TILE_LONG_ROW = 128           # SPARC_TILE_LONG_ROW: rows with more in-window entries get a whole wavefront
 TILE_MAX_RUN = 65535          # entries of one row before / behind its window
-TILE_MAX_OUTSIDE_SHARE = 0.5  # a batch with a larger share of its entries outside the windows is not tiled
 N_CU = 256
 
 
@@ -257,6 +256,7 @@ class ClusterBatch:
         self.device = device
         self._windows = plan_windows(m, cluster_sizes)
         self._tiles = {}
+        self._measured = {}
         self._window_ranges = None
         self._prepare(eps)
         return self
@@ -281,32 +281,35 @@ class ClusterBatch:
         return self._window_ranges
 
     # ---- tiling policy ---------------------------------------------------------------------
-    tile_vec = 2            # floats per lane of the windowed kernel (2: 32-float slabs, 4: 64-float slabs)
+    tile_vec = None         # floats per lane of the windowed kernel (2: 32-float slabs, 4: 64-float slabs; None: by k)
     tile_threads = None     # workgroup size (None: 512 for vec 2, 1024 for vec 4)
     tile_target_wgs = None  # workgroups to aim for (None: two per CU for vec 2, one for vec 4)
+    # A batch with a larger share of its entries outside the windows runs on the row kernel: outside entries are
+    # gathered from L2 by a quarter wave each, which the row kernel does better with whole waves.  Measured on an
+    # MI355X, k = 47..64: 0.5 % outside, windowed 19 us vs 39 us; 4 %, a tie; 23 %, 33 us vs 26 us.
+    tile_max_outside_share = 0.08
 
     @classmethod
     def tile_geometry(cls, k: int, training: bool):
         """(vec, kp, n_slabs) of the windowed kernel for spectral dimension k, or None when the pass
         runs on the row kernel.  Training pass: slabs of 8 vec columns of each half, kp = k rounded up to
         that; forward-only pass: slabs of 16 vec columns, for k > 16."""
-        if not cls.use_tiles:
+        if not cls.use_tiles or (not training and k <= 16):
             return None
         vec = cls.tile_vec
-        if training:
-            hw = 8 * vec
-        else:
-            if k <= 16:
-                return None
-            hw = 16 * vec
+        if vec is None:     # the wide lanes when they bring no extra column padding (half as many slabs and instructions)
+            narrow = 8 * 2 if training else 16 * 2
+            vec = 4 if (-(-k // narrow)) % 2 == 0 else 2
+        hw = 8 * vec if training else 16 * vec
         kp = -(-k // hw) * hw
         return vec, kp, kp // hw
 
     def tiling(self, k: int, training: bool):
         """The _lib.Tiling of this batch for the given pass (cached), or None: no windowed kernel for this
-        k, or too large a share of the batch's entries lies outside the windows."""
+        k, too large a share of the batch's entries outside the windows, or the row kernel measured faster
+        (warm(measure=True))."""
         geo = self.tile_geometry(k, training)
-        if geo is None:
+        if geo is None or self._measured.get((k, bool(training))) == "rows":
             return None
         vec, kp, n_slabs = geo
         threads = self.tile_threads or (512 if vec == 2 else 1024)
@@ -327,7 +330,7 @@ class ClusterBatch:
             return None
         p0, lo, hi, p1 = self._in_window_ranges()
         n_in, n_out = hi - lo, (lo - p0) + (p1 - hi)
-        if n_out.sum() > TILE_MAX_OUTSIDE_SHARE * max(self.nnz, 1):
+        if n_out.sum() > self.tile_max_outside_share * max(self.nnz, 1):
             return None
         pl = plan_tiles(self._windows, n_in, n_out, n_slabs, threads, target)
         if len(pl["slot_L"]) and (pl["slot_L"].max() > 0xFFFF or pl["slot_O"].max() > 0x7FFF) or \
@@ -400,9 +403,26 @@ class ClusterBatch:
                                           _ptr(ws), nbytes, _stream()), "sparc_affinity_prep")
         self.d, self.cw, self.rho = vec[0], vec[1], vec[2]
 
-    def warm(self, k: int, training: bool = True):
-        """Build the tiling for spectral dimension k now (it is otherwise built on first use)."""
-        self.tiling(k, training)
+    def warm(self, k: int, training: bool = True, measure: bool = False, reps: int = 5):
+        """Build the tiling for spectral dimension k now (it is otherwise built on first use).  measure: when
+        the batch has a tiling, time its pass on both kernels (reps calls each, about a millisecond in all) and
+        keep the faster one for this (k, training); both produce the same result to rounding, so the choice
+        only moves time."""
+        if self.tiling(k, training) is not None and measure and (k, bool(training)) not in self._measured:
+            Y = torch.randn(self.m, k, device=self.device)
+            took = {}
+            for name in ("tiles", "rows"):
+                self._measured[(k, bool(training))] = name
+                self.lap(Y, training)
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                ev[0].record()
+                for _ in range(reps):
+                    self.lap(Y, training)
+                ev[1].record()
+                ev[1].synchronize()
+                took[name] = ev[0].elapsed_time(ev[1])
+            self._measured[(k, bool(training))] = min(took, key=took.get)
+            self.measured_ms = {n: v / reps for n, v in took.items()}
         return self
 
     # ---- per-step work -------------------------------------------------------------------

@@ -185,9 +185,10 @@ def test_tiled_spmm_matches_scipy(dev, big_fixture, flavour, width):
 
 
 @pytest.mark.parametrize("hint", ["clusters", "none", "halves"])
-def test_tiled_windows_that_cut_clusters(dev, hint):
+def test_tiled_windows_that_cut_clusters(dev, hint, monkeypatch):
     """Windows that do not follow the clusters (no hint: equal cuts; two oversized clusters: split evenly)
-    put many entries outside their row's window; short rows keep the batch under the planner's limit."""
+    put many entries outside their row's window; the planner's limit on that share is lifted here so that
+    the windowed kernel's outside path carries them."""
     from sparc_amd.graph import ClusterBatch
     rng = np.random.default_rng(11)
     sizes = [500, 480, 510, 470, 490]
@@ -199,6 +200,7 @@ def test_tiled_windows_that_cut_clusters(dev, hint):
     Y = rng.standard_normal((m, k)).astype(np.float32)
     loss_o, g_o, _, _ = O.lap_forward_operator(A, O.affinity_prep_operator(A), Y.astype(np.float64))
     cs = {"clusters": sizes, "none": None, "halves": [m // 2, m - m // 2]}[hint]
+    monkeypatch.setattr(ClusterBatch, "tile_max_outside_share", 1.0)   # the windowed kernel whatever the share
     b = ClusterBatch.from_support(s, dev, cluster_sizes=cs)
     loss, grad = b.lap(torch.tensor(Y, device=dev), True)
     assert rel(loss.item(), loss_o) < TOL and rel(grad.cpu().numpy(), g_o) < TOL
@@ -208,8 +210,8 @@ def test_tiled_windows_that_cut_clusters(dev, hint):
 
 
 def test_untileable_batch_falls_back_to_row_kernel(dev):
-    """A batch without cluster structure has no tiling (more than 5 % of its rows reach outside their
-    window more than twice): lap() then runs the row kernel, which must match the oracle too."""
+    """A batch without cluster structure has no tiling (most of its entries lie outside their row's
+    window): lap() then runs the row kernel, which must match the oracle too."""
     from sparc_amd.graph import ClusterBatch
     rng = np.random.default_rng(3)
     m, k = 1500, 47
@@ -232,6 +234,7 @@ def test_full_size_batch_tiled_equals_row_kernel(dev, workload, min_m, min_nnz, 
     size-independent properties of the loss."""
     from sparc_amd.graph import ClusterBatch
     from sparc_amd import synth
+    monkeypatch.setattr(ClusterBatch, "tile_max_outside_share", 1.0)   # Reddit's share is above the planner's limit
     b, k = synth.shape_batch(workload, dev)
     assert b.m >= min_m and b.nnz >= min_nnz, (b.m, b.nnz)
     cen = tiling_census(b, k, True)
@@ -248,3 +251,26 @@ def test_full_size_batch_tiled_equals_row_kernel(dev, workload, min_m, min_nnz, 
     assert loss.item() >= 0
     inner = (grad.double() * Y.double()).sum().item()       # gradient of a quadratic form: <grad, Y> = 2 loss
     assert abs(inner - 2 * loss.item()) / loss.item() < 1e-4
+
+
+def test_kernel_choice_by_share_and_by_measurement(dev, monkeypatch):
+    """The planner's rule (share of entries outside the windows) sends the Amazon2M-shape batch to the
+    windowed kernel and the Reddit-shape batch to the row kernel; warm(measure=True) times both kernels on
+    a batch that has a tiling and keeps the faster, and lap() then follows that choice."""
+    from sparc_amd.graph import ClusterBatch
+    from sparc_amd import synth
+    ba, ka = synth.shape_batch("amazon2m", dev)
+    br, kr = synth.shape_batch("reddit", dev)
+    assert ba.tiling(ka, True) is not None and br.tiling(kr, True) is None
+    ba.warm(ka, True, measure=True)
+    choice = ba._measured[(ka, True)]
+    assert choice in ("tiles", "rows") and set(ba.measured_ms) == {"tiles", "rows"}
+    assert choice == min(ba.measured_ms, key=ba.measured_ms.get)
+    assert (ba.tiling(ka, True) is None) == (choice == "rows")
+    monkeypatch.setattr(ClusterBatch, "tile_max_outside_share", 1.0)
+    br2, _ = synth.shape_batch("reddit", dev)
+    br2.warm(kr, True, measure=True)
+    Y = torch.randn(br2.m, kr, device=dev)
+    l1, g1 = br2.lap(Y, True)                    # whichever kernel was kept
+    l0, g0 = br.lap(Y, True)                     # the row kernel
+    assert rel(l1.item(), l0.item()) < 1e-5 and rel(g1.cpu().numpy(), g0.cpu().numpy()) < 1e-5

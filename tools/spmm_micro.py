@@ -18,7 +18,7 @@ workload = os.environ.get("WORKLOAD", "amazon2m")
 bsize = int(os.environ.get("BSIZE", "0")) or None
 b, k = synth.shape_batch(workload, dev, bsize=bsize)
 k = int(os.environ.get("K", k))
-ClusterBatch.tile_vec = int(os.environ.get("VEC", "2"))
+ClusterBatch.tile_vec = int(os.environ.get("VEC", "0")) or None
 ClusterBatch.tile_threads = int(os.environ.get("THREADS", "0")) or None
 ClusterBatch.tile_target_wgs = int(os.environ.get("WGS", "0")) or None
 p0, lo, hi, p1 = b._in_window_ranges()

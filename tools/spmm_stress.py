@@ -96,7 +96,8 @@ def main():
             b.val = torch.ones(b.nnz, dtype=torch.float32, device=dev)
             b.valT = None
             b._windows = plan_windows(g.n, np.diff(bounds.cpu().numpy()))
-            b._tiles, b._window_ranges = {}, None
+            b._tiles, b._measured, b._window_ranges = {}, {}, None
+            b.tile_max_outside_share = 1.0           # the windowed kernel whatever the share of cross-cluster entries
             t0 = time.perf_counter()
             t = b._plan(4, 64, 1, False, 1024, 256)
             torch.cuda.synchronize()

@@ -10,7 +10,7 @@ from sparc_amd._lib import lib
 from sparc_amd.graph import ClusterBatch
 dev = torch.device("cuda:0")
 b, k = synth.shape_batch(os.environ.get("WORKLOAD", "amazon2m"), dev, bsize=int(os.environ.get("BSIZE", "0")) or None)
-ClusterBatch.tile_vec = int(os.environ.get("VEC", "2"))
+ClusterBatch.tile_vec = int(os.environ.get("VEC", "0")) or None
 t = b.tiling(k, True)
 Y = torch.randn(b.m, k, device=dev)
 for _ in range(3):
