@@ -147,6 +147,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (testing only)")
     ap.add_argument("--cpu-sample", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hip-graph", action="store_true", help="replay whole steps as HIP graphs (one GPU; small batches)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -187,7 +188,7 @@ def main():
     log(f"[bench] graph: {n} nodes, {int(graph.indices.numel())} stored entries, {len(nodes_of)} batches, {t_graph:.1f}s")
 
     mine = shard_batches(len(nodes_of), world, rank)[:args.batches_per_rank]
-    trainer = ShardedSpectralTrainer(arch, din, dev, lr=1e-3, seed=0)
+    trainer = ShardedSpectralTrainer(arch, din, dev, lr=1e-3, seed=0, hip_graph=args.hip_graph)
     t0 = time.perf_counter()
     for b in mine:
         pt = nodes_of[b]
@@ -217,7 +218,8 @@ def main():
     if world > 1:
         dist.barrier()
     # HIP events around the inner row-gather passes (epilogue 1), on the launch stream
-    check(lib.sparc_profile_begin(1, args.steps), "sparc_profile_begin")   # one event pair per step: both inner passes
+    if not args.hip_graph:   # (events recorded inside a captured graph carry no time: measured after the run instead)
+        check(lib.sparc_profile_begin(1, args.steps), "sparc_profile_begin")   # one event pair per step: both inner passes
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     nodes = 0
@@ -237,6 +239,15 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     tot_ms, launches = ctypes.c_double(0.0), ctypes.c_int64(0)
+    if args.hip_graph:       # the same event bracket around the inner passes of eager calls on batch 0
+        b0 = trainer.batches[0]
+        Y0 = torch.randn(b0.m, k, device=dev)
+        for _ in range(3):
+            b0.lap(Y0, True)
+        check(lib.sparc_profile_begin(1, args.steps), "sparc_profile_begin")
+        for _ in range(args.steps):
+            b0.lap(Y0, True)
+        torch.cuda.synchronize()
     check(lib.sparc_profile_end(ctypes.byref(tot_ms), ctypes.byref(launches)), "sparc_profile_end")
 
     stats = torch.tensor([elapsed, float(nodes)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
@@ -268,7 +279,7 @@ def main():
                                    f"{shape['bsize']} clusters/batch, diag_lambda={lam}, MLP {din}-1024-1024-512-{k}",
                        "batch_nodes": int(np.mean(ms)), "batch_nnz": int(np.mean(nnzs)),
                        "batches_per_gpu": nb, "prep_seconds_per_batch": t_prep / max(nb, 1),
-                       "parallelism": f"dp{world} (cluster batches sharded, flat-gradient all-reduce)",
+                       "parallelism": f"dp{world} (cluster batches sharded, flat-gradient all-reduce)" + (", steps replayed as HIP graphs" if args.hip_graph else ""),
                        "mean_loss": final_loss},
             "roofline": {"bound": "hbm", "kernel": kernel,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

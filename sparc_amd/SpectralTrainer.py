@@ -148,7 +148,13 @@ class SpectralTrainer:
         self.criterion = SpectralNetLoss()
         self.spectral_net = SpectralNetModel(self.architecture, input_dim=self.features_batches[0].shape[1],
                                              device=self.device, orth_mode=self.orth_mode).to(self.device)
-        self.optimizer = optim.Adam(self.spectral_net.parameters(), lr=self.lr, fused=True)  # one launch per step
+        # spectral.hip_graph (not a reference key; default off): whole steps replayed as HIP graphs, one launch per step
+        hip_graph = bool(self.spectral_config.get("hip_graph", False))
+        if hip_graph:
+            lr_t = torch.tensor(float(self.lr), device=self.device)
+            self.optimizer = optim.Adam(self.spectral_net.parameters(), lr=lr_t, fused=True, capturable=True)
+        else:
+            self.optimizer = optim.Adam(self.spectral_net.parameters(), lr=self.lr, fused=True)  # one launch per step
         self.scheduler = optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, mode="min", factor=self.lr_decay,
                                                               patience=self.patience)
         k = self.architecture["output_dim"]
@@ -160,6 +166,11 @@ class SpectralTrainer:
                for i, s in enumerate(self.support_batches)]
         vfeats = [f.to(self.device, dtype=torch.float32) for f in self.val_features_batches]
         vsup = [self._get_support_matrix(s).warm(k, training=False, measure=True) for s in self.val_support_batches]
+
+        graphed = None
+        if hip_graph:
+            from .stepgraph import GraphedSteps
+            graphed = GraphedSteps(self.spectral_net, self.criterion, self.optimizer, feats, sup, k, self.device)
 
         min_val_loss = 1000000000
         batches = len(feats)
@@ -174,6 +185,9 @@ class SpectralTrainer:
 
                 # Orthogonality step (autograd stays on, as in the reference :222-223) and the
                 # forward of the gradient step (:232), one MLP pass over both batches
+                if graphed is not None:
+                    train_loss += graphed.step(pid, pid_2, perm_2[:k])
+                    continue
                 self.spectral_net.train()
                 self.optimizer.zero_grad()
                 Y = self.spectral_net.forward_pair(feats[pid_2], feats[pid], top_idx=perm_2[:k])
@@ -196,7 +210,10 @@ class SpectralTrainer:
                                                "(the reference's torch.inverse(R) fails on the same input)")
 
             self.scheduler.step(valid_loss)
-            current_lr = self.optimizer.param_groups[0]["lr"]
+            current_lr = float(self.optimizer.param_groups[0]["lr"])
+            if hip_graph and self.optimizer.param_groups[0]["lr"] is not lr_t:   # the graphs read the rate from lr_t
+                lr_t.fill_(current_lr)
+                self.optimizer.param_groups[0]["lr"] = lr_t
             if current_lr <= self.spectral_config["min_lr"]:
                 break
             print(f"Epoch: {epoch + 1}/{self.epochs}, Train Loss: {train_loss / batches:.7f}, "

@@ -108,7 +108,8 @@ class ShardedSpectralTrainer:
     default they are the MI355X SpectralNetModel and SpectralNetLoss."""
 
     def __init__(self, architecture: dict, input_dim: int, device, lr: float = 1e-3, orth_mode: str = "reference",
-                 group=None, seed: Optional[int] = 0, net=None, criterion=None, fused_adam: bool = True):
+                 group=None, seed: Optional[int] = 0, net=None, criterion=None, fused_adam: bool = True,
+                 hip_graph: bool = False):
         self.device = torch.device(device)
         if seed is not None:
             torch.manual_seed(seed)  # identical initial weights on every rank
@@ -126,7 +127,13 @@ class ShardedSpectralTrainer:
             for p in self.net.parameters():
                 broadcast(p.data, 0, group)
         self.params = list(self.net.parameters())
-        self.optimizer = torch.optim.Adam(self.net.parameters(), lr=lr, fused=fused_adam)
+        self.hip_graph = bool(hip_graph) and not self.distributed   # whole steps replayed as HIP graphs (one GPU)
+        if self.hip_graph:
+            self.lr = torch.tensor(float(lr), device=self.device)
+            self.optimizer = torch.optim.Adam(self.net.parameters(), lr=self.lr, fused=True, capturable=True)
+        else:
+            self.optimizer = torch.optim.Adam(self.net.parameters(), lr=lr, fused=fused_adam)
+        self._graphed = None
         self.criterion = criterion
         self.reducer = LayerwiseReducer(group) if self.distributed else None
         self.features = []
@@ -143,6 +150,12 @@ class ShardedSpectralTrainer:
         while the backward runs when the MLP reports its layers (ops.GRAD_READY_HOOK), in one bucket after
         the backward otherwise."""
         from . import ops
+        if self.hip_graph:
+            if self._graphed is None:
+                from .stepgraph import GraphedSteps
+                self._graphed = GraphedSteps(self.net, self.criterion, self.optimizer, self.features, self.batches,
+                                             self.k, self.device)
+            return self._graphed.step(pid, pid_2, top_idx)
         net = self.net
         net.train()
         self.optimizer.zero_grad(set_to_none=True)   # autograd hands its gradients over as they are: no accumulation

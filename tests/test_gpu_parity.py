@@ -504,8 +504,10 @@ def test_forward_pair_equals_two_forwards(dev, golden):
         assert rel(p.grad.cpu().numpy(), g["grad." + name]) < (5e-4 if name == "layers.3.0.bias" else 5e-5), name
 
 
-def test_trainer_end_to_end_matches_reference(dev, golden, tmp_path, monkeypatch, capsys):
-    """Two epochs of SpectralTrainer.train with the reference's seeds and data."""
+@pytest.mark.parametrize("hip_graph", [False, True])
+def test_trainer_end_to_end_matches_reference(dev, golden, tmp_path, monkeypatch, capsys, hip_graph):
+    """Two epochs of SpectralTrainer.train with the reference's seeds and data; eagerly, and with every step
+    replayed as a HIP graph (spectral.hip_graph)."""
     from sparc_amd.SpectralTrainer import SpectralTrainer
     g = golden("g8_trainer.npz")
     monkeypatch.chdir(tmp_path)
@@ -515,7 +517,8 @@ def test_trainer_end_to_end_matches_reference(dev, golden, tmp_path, monkeypatch
     vs = [(g[f"vcoords{b}"], g[f"vvalues{b}"], tuple(int(x) for x in g[f"vshape{b}"])) for b in range(2)]
     cfg = {"dataset": "golden", "spectral": {
         "architecture": {"n_layers": 4, "hidden_dim1": 32, "hidden_dim2": 32, "hidden_dim3": 16, "output_dim": 6},
-        "epochs": 2, "lr": 1e-3, "lr_decay": 0.1, "min_lr": 1e-7, "batch_size": 1024, "n_clusters": 6, "patience": 10}}
+        "epochs": 2, "lr": 1e-3, "lr_decay": 0.1, "min_lr": 1e-7, "batch_size": 1024, "n_clusters": 6, "patience": 10,
+        "hip_graph": hip_graph}}
     torch.manual_seed(0)
     np.random.seed(0)
     tr = SpectralTrainer(cfg, dev)
@@ -783,3 +786,34 @@ def test_cora_batch_matches_reference(dev, golden):
             assert rel(SpectralNetLoss()(b, Y.detach(), is_normalized=False).item(), g["loss_plain"]) < TOL
         finally:
             ClusterBatch.use_tiles = True
+
+
+def test_hip_graph_steps_match_eager_steps(dev):
+    """Whole steps replayed as HIP graphs (sparc_amd/stepgraph.py) follow the eager trainer: same losses and
+    weights over eight steps that revisit every (gradient batch, orthogonality batch) pair of two batches,
+    with a different permutation head every step."""
+    from sparc_amd import synth
+    from sparc_amd.graph import ClusterBatch
+    from sparc_amd.parallel import ShardedSpectralTrainer
+    k, din = 12, 20
+    arch = {"n_layers": 6, "hidden_dim1": 64, "hidden_dim2": 64, "hidden_dim3": 32, "output_dim": k}
+    graph, bounds = synth.planted_cluster_graph(3000, 12000, 12, dev, seed=3)
+    nodes_of, cluster_ids = synth.cluster_batches(bounds, 6, seed=0, return_clusters=True)
+    runs = {}
+    for mode in (False, True):
+        tr = ShardedSpectralTrainer(arch, din, dev, lr=1e-3, seed=5, hip_graph=mode)
+        for b in range(2):
+            coords, values, shp, _ = graph.subblock(nodes_of[b], mode=2, binarize=False, diag_lambda=0.01)
+            tr.add_batch(synth.block_features(nodes_of[b], bounds, din, 12),
+                         ClusterBatch.from_device_coo(shp[0], coords, values).warm(k))
+        rng = np.random.RandomState(0)
+        losses = []
+        for s in range(8):
+            pid, pid_2 = s % 2, (s // 2) % 2
+            head = rng.permutation(tr.batches[pid_2].m)[:k]
+            losses.append(float(tr.step(pid, pid_2, head)))
+        runs[mode] = (np.array(losses), torch.cat([p.detach().flatten() for p in tr.params]).cpu().numpy())
+    assert len(tr._graphed.graphs) == 4
+    assert np.all(np.isfinite(runs[True][0]))
+    assert rel(runs[True][0], runs[False][0]) < 1e-5, (runs[True][0], runs[False][0])
+    assert rel(runs[True][1], runs[False][1]) < 1e-5
