@@ -1,0 +1,102 @@
+"""Checks on the gfx950 machine code of the windowed SpMM kernels (compiled here with the flags of
+sparc_amd.build; no GPU needed):
+
+* a DPP instruction must not read a register that a vector instruction wrote in the two instructions before it
+  (gfx9 needs two wait states there; the broadcasts are compiler builtins so that the compiler provides them);
+* the asynchronous global->LDS staging must be complete (s_waitcnt vmcnt(0)) before the workgroup barrier that
+  publishes the window;
+* no kernel of the per-step path spills more than a few registers to scratch memory.
+"""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def spmm_asm(tmp_path_factory):
+    from sparc_amd import build
+    out = tmp_path_factory.mktemp("isa") / "spmm.s"
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    flags = [f for f in build.FLAGS if f != "-fPIC"]
+    subprocess.run([hipcc] + flags + ["-S", "--cuda-device-only", "-o", str(out),
+                                      os.path.join(ROOT, "sparc_amd", "csrc", "spmm.hip")], check=True, cwd=str(out.parent))
+    text = out.read_text()
+    kernels = {}
+    for m in re.finditer(r"^(_Z\w*spmm_win\w*):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
+        body = [l.split(";")[0].strip() for l in m.group(2).splitlines()]     # drop comments
+        kernels[m.group(1)] = [l for l in body if l and not l.startswith(".") and not l.endswith(":")]
+    assert len(kernels) >= 16, "spmm_win instantiations not found in the assembly"
+    return text, kernels
+
+
+def _regs(operand):
+    """Register numbers named by one operand (v12 or v[12:15])."""
+    m = re.fullmatch(r"v(\d+)", operand)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", operand)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    return set()
+
+
+def dpp_hazards(ins):
+    """(count of DPP instructions, list of (writer, reader, wait states) violations) of one instruction list."""
+    n_dpp, bad = 0, []
+    for i, line in enumerate(ins):
+        op, _, rest = line.partition(" ")
+        if not op.endswith("_dpp"):
+            continue
+        n_dpp += 1
+        ops = [o.strip() for o in rest.split(" row_")[0].split(",")]
+        src = _regs(ops[1])                       # the DPP operand is src0
+        waited = 0
+        for prev in reversed(ins[max(0, i - 4):i]):
+            pop, _, prest = prev.partition(" ")
+            if pop == "s_nop":
+                waited += int(prest.strip()) + 1
+            else:
+                if pop.startswith("v_") and (_regs(prest.split(",")[0].strip()) & src):
+                    bad.append((prev, line, waited))
+                waited += 1
+            if waited >= 2:
+                break
+    return n_dpp, bad
+
+
+def test_no_dpp_read_within_two_wait_states_of_a_vector_write(spmm_asm):
+    _, kernels = spmm_asm
+    # the checker itself: one wait state is a violation, a vector write two instructions earlier or an s_nop 1 is not
+    add = "v_add_u32_dpp v0, v18, v73 row_newbcast:0 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+    assert dpp_hazards(["v_lshlrev_b32 v18, 8, v44", "s_or_b64 exec, exec, s[4:5]", add])[1]
+    assert dpp_hazards(["v_mov_b32 v18, v2", add])[1]
+    assert not dpp_hazards(["v_mov_b32 v18, v2", "s_nop 1", add])[1]
+    assert not dpp_hazards(["v_mov_b32 v18, v2", "v_mov_b32 v3, v2", "v_mov_b32 v4, v2", add])[1]
+    total = 0
+    for name, ins in kernels.items():
+        n, bad = dpp_hazards(ins)
+        total += n
+        assert not bad, (name, bad[:3])
+    assert total > 1000     # the gather of every instantiation is DPP based: the check saw it
+
+
+def test_lds_staging_is_waited_for_before_the_barrier(spmm_asm):
+    _, kernels = spmm_asm
+    for name, ins in kernels.items():
+        bar = next(i for i, l in enumerate(ins) if l.startswith("s_barrier"))
+        last_dma = max(i for i, l in enumerate(ins[:bar]) if "global_load_lds" in l)
+        between = ins[last_dma:bar]
+        assert any(re.match(r"s_waitcnt vmcnt\(0\)", l) for l in between), name
+
+
+def test_per_step_kernels_do_not_spill(spmm_asm):
+    text, _ = spmm_asm
+    spills = {}
+    for m in re.finditer(r"\.name:\s+(\S*spmm_win\S*)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text):
+        spills[m.group(1)] = int(m.group(2))
+    assert len(spills) >= 16
+    assert max(spills.values()) <= 8, {k: v for k, v in spills.items() if v > 8}

@@ -23,6 +23,8 @@ torch.cuda.synchronize()
 lib.sparc_debug_stamps(None)
 s = buf.cpu().numpy().reshape(t.ndesc, 16, 4)
 nw = t.threads // 64
+if os.environ.get("DUMP"):   # raw stamps and descriptors for offline analysis
+    np.savez(os.environ["DUMP"], stamps=s[:, :nw], desc=t.desc, slot_L=t.plan["slot_L"], slot_O=t.plan["slot_O"])
 s = s[:, :nw]
 live = s[:, 0, 3] > 0
 s = s[live]
