@@ -271,6 +271,16 @@ int sparc_subblock_fill(int64_t n, const int64_t* indptr, const int32_t* indices
                         int32_t* coords, double* values,
                         void* ws, size_t ws_bytes, sparc_stream_t stream);
 
+/* ---- token lists: the selection step of the brute-force nearest-neighbour search ------
+ * Replaces the sort inside sklearn's NearestNeighbors.kneighbors as
+ * implementations/SPARCphormer/utils.py:270-273 uses it (only prefixes of 2, 4, ... of the 16 384
+ * neighbours are consumed, :288-296): for every row of the float64 distance matrix D [rows][n]
+ * (row stride ld), out[row][i] = the ranks[i]-th smallest entry of the row (1-based ranks in
+ * ascending order on the HOST, at most 32 of them, clamped to n; equal entries count separately).
+ * A prefix of e neighbours is then {j : D[row][j] <= out[row][i]}.  No workspace; D is only read. */
+int sparc_row_rank_values(int64_t rows, int64_t n, const double* D, int64_t ld, int nranks,
+                          const int64_t* ranks, double* out, sparc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,8 +9,8 @@ and averages feature rows prefix by prefix.  Here a chunk of query rows gets its
 row from one GEMM (||a||^2 + ||b||^2 - 2 a.b in float64), the prefix lengths become per-row
 distance thresholds (a k-th-smallest selection on the sorted row), and every prefix mean is a
 product of a 0/1 membership matrix with the feature matrix: K GEMMs per chunk instead of
-n x 16 384 row gathers.  Only the min(2^14, n) smallest distances of a row are ordered (a top-k
-selection, not a sort of the whole row).
+n x 16 384 row gathers.  The thresholds come from a selection kernel (sparc_row_rank_values: bucket
+refinement on the order-preserving integer image of the distances, no row is sorted).
 
 Ties: nodes at exactly equal distance on a prefix boundary are all counted and the mean divides by
 the actual count, which is deterministic and independent of the node numbering.  The reference's
@@ -21,13 +21,31 @@ without ties they agree to rounding (tests/golden/g10_tokens.npz).
 """
 from __future__ import annotations
 
+import ctypes
+
 import numpy as np
 import torch
 
-from .graph import require_gpu
+from ._lib import check, lib
+from .graph import _ptr, _stream, require_gpu
 
 PREFIX = [1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768]
 MAX_NEIGHBOURS = 2 ** 14
+
+
+def row_rank_values(D: torch.Tensor, ranks) -> torch.Tensor:
+    """out[i, j] = the ranks[j]-th smallest entry of row i of the float64 matrix D (1-based, ascending ranks):
+    the selection kernel of libsparc_hip.so, no row is sorted."""
+    if D.dtype != torch.float64 or D.dim() != 2 or D.stride(1) != 1:
+        raise ValueError("D must be a float64 matrix with contiguous rows")
+    require_gpu(D.device)
+    ranks = [int(r) for r in ranks]
+    out = torch.empty(D.shape[0], len(ranks), dtype=torch.float64, device=D.device)
+    host = (ctypes.c_int64 * len(ranks))(*ranks)
+    with torch.cuda.device(D.device):
+        check(lib.sparc_row_rank_values(D.shape[0], D.shape[1], _ptr(D), D.stride(0), len(ranks), host, _ptr(out), _stream()),
+              "sparc_row_rank_values")
+    return out
 
 
 def spectral_token_lists(spectral_encoding, features, K: int, device=None, chunk_rows: int = 2048) -> torch.Tensor:
@@ -46,11 +64,10 @@ def spectral_token_lists(spectral_encoding, features, K: int, device=None, chunk
         d2 = (sq[a:a + chunk_rows, None] + sq[None, :] - 2.0 * (q @ E.t())).clamp_(min=0.0)
         rows = torch.arange(q.shape[0], device=device)
         d2[rows, a + rows] = -1.0                       # a node is its own nearest neighbour
-        # the kmax smallest distances of every row in ascending order
-        srt = torch.topk(d2, kmax, dim=1, largest=False, sorted=True).values if kmax < n else torch.sort(d2, dim=1).values
+        thr = row_rank_values(d2, ends)                 # [rows, K]: the e-th smallest distance of every row
         tok = torch.empty(q.shape[0], K, nf, dtype=torch.float32, device=device)
         for j, e in enumerate(ends):
-            member = (d2 <= srt[:, e - 1:e]).to(torch.float32)
+            member = (d2 <= thr[:, j:j + 1]).to(torch.float32)
             tok[:, j, :] = (member @ Fm) / member.sum(1, keepdim=True)
         out[a:a + chunk_rows, 1:, :] = tok.cpu()
     return out

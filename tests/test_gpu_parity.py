@@ -691,6 +691,40 @@ def test_token_lists_match_reference_golden(dev, golden):
     assert np.abs(t.numpy() - g["tokens"]).max() < 1e-5
 
 
+@pytest.mark.parametrize("kind", ["normal", "ties", "tiny", "negatives"])
+def test_row_rank_values_bit_exact(dev, kind):
+    """The selection kernel against numpy's sort, bit for bit: continuous values (buckets refined once or
+    twice), long runs of equal values straddling the ranks (refined down to the last key bit), rows shorter than the
+    ranks, negative entries and zeros of both signs (the integer image of the doubles must keep their order)."""
+    from sparc_amd.tokens import row_rank_values
+    rng = np.random.default_rng(5)
+    rows, n = 37, 23011
+    if kind == "normal":
+        D = rng.standard_normal((rows, n)) ** 2
+        D[np.arange(rows), np.arange(rows)] = -1.0
+    elif kind == "ties":
+        D = rng.integers(0, 7, (rows, n)).astype(np.float64) * 0.125      # seven distinct values: every rank in a long run
+        D[:, :5] = rng.standard_normal((rows, 5))
+    elif kind == "tiny":
+        n = 9
+        D = rng.standard_normal((rows, n))
+    else:
+        D = rng.standard_normal((rows, n)) * 10.0 ** rng.integers(-300, 300, (rows, n))
+        D[:, 7] = 0.0
+        D[:, 8] = -0.0
+        D[:, 9] = np.inf
+    ranks = [1, 2, 4, 8, 16, 300, 2048, 4097, 16384, n]
+    ranks = sorted(set(min(r, n) for r in ranks)) if kind != "tiny" else [1, 2, 4, 8, 16, 300]
+    got = row_rank_values(torch.tensor(D, device=dev), ranks).cpu().numpy()
+    srt = np.sort(D, axis=1)
+    want = np.stack([srt[:, min(r, n) - 1] for r in ranks], axis=1)
+    assert np.array_equal(got, want)      # -0.0 == 0.0: the two zeros compare equal, as they do in the membership test
+    # a strided view (rows of a larger matrix)
+    big = torch.tensor(np.concatenate([D, D], axis=1), device=dev)
+    got2 = row_rank_values(big[:, :n], ranks).cpu().numpy()
+    assert np.array_equal(got2, want)
+
+
 def test_token_lists_match_oracle_larger(dev):
     from sparc_amd.tokens import spectral_token_lists
     rng = np.random.default_rng(8)

@@ -25,3 +25,20 @@ torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print(json.dumps({"nodes": n, "embedding_dim": k, "features": nf, "prefix_means": K, "seconds": dt,
                   "nodes_per_s": n / dt}), flush=True)
+
+# the selection step alone: the kernel against torch.topk (sorted) on one chunk of distance rows
+from sparc_amd.tokens import row_rank_values  # noqa: E402
+dev = torch.device("cuda:0")
+Ed = torch.tensor(E, device=dev)
+sq = (Ed * Ed).sum(1)
+d2 = (sq[:2048, None] + sq[None, :] - 2.0 * (Ed[:2048] @ Ed.t())).clamp_(min=0.0)
+ends = [min(2 ** (j + 1), 2 ** 14) for j in range(K)]
+for name, fn in (("kernel", lambda: row_rank_values(d2, ends)),
+                 ("torch.topk", lambda: torch.topk(d2, 2 ** 14, dim=1, largest=False, sorted=True).values)):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    print(json.dumps({"selection": name, "rows": 2048, "ms": (time.perf_counter() - t0) / 3 * 1e3}), flush=True)
