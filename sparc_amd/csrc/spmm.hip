@@ -649,29 +649,34 @@ __global__ __launch_bounds__(256) void lap_scale(int64_t m, int k, int64_t ldy, 
     }
 }
 
-// M1 = C (V^T Yn), M2 = C^T (U^T X2): the 3 x KP matrices of the rank-3 correction.
-__global__ void lap_colsum_finish(int KP, int nparts, bool dual, const float* __restrict__ colpart,
+// M1 = C (V^T Yn), M2 = C^T (U^T X2): the 3 x KP matrices of the rank-3 correction.  Launched with
+// split x 6 KP threads (split <= FINISH_SPLIT): the block partials of one column sum are dealt to `split`
+// threads (fixed assignment, eight independent chains each) and combined in a fixed order.
+constexpr int FINISH_SPLIT = 4;
+__global__ void lap_colsum_finish(int KP, int nparts, int split, bool dual, const float* __restrict__ colpart,
                                   const double* __restrict__ coupling, float* __restrict__ M12) {
-    __shared__ double S[6][SPARC_MAX_K];
-    const int q = threadIdx.x / KP, col = threadIdx.x % KP;
+    __shared__ double S[FINISH_SPLIT][6][SPARC_MAX_K];
+    const int e = threadIdx.x % (6 * KP), share = threadIdx.x / (6 * KP);
+    const int q = e / KP, col = e % KP;
     const int ns = dual ? 6 : 3;
     if (q < ns) {
         double t[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // eight independent chains, fixed order
-        int b = 0;
-        for (; b + 8 <= nparts; b += 8) {
+        int b = share;
+        for (; b + 7 * split < nparts; b += 8 * split) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] += colpart[(static_cast<int64_t>(b + u) * 6 + q) * KP + col];
+            for (int u = 0; u < 8; ++u) t[u] += colpart[(static_cast<int64_t>(b + u * split) * 6 + q) * KP + col];
         }
-        for (; b < nparts; ++b) t[0] += colpart[(static_cast<int64_t>(b) * 6 + q) * KP + col];
-        S[q][col] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+        for (; b < nparts; b += split) t[0] += colpart[(static_cast<int64_t>(b) * 6 + q) * KP + col];
+        S[share][q][col] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
     }
     __syncthreads();
-    if (q < ns) {
+    if (share == 0 && q < ns) {
         double t = 0.0;
-        if (q < 3) {
-            for (int b = 0; b < 3; ++b) t += coupling[q * 3 + b] * S[b][col];
-        } else {
-            for (int b = 0; b < 3; ++b) t += coupling[b * 3 + (q - 3)] * S[3 + b][col];
+        for (int b = 0; b < 3; ++b) {
+            const int src = q < 3 ? b : 3 + b;
+            double sum = S[0][src][col];
+            for (int h = 1; h < split; ++h) sum += S[h][src][col];
+            t += (q < 3 ? coupling[q * 3 + b] : coupling[b * 3 + (q - 3)]) * sum;
         }
         M12[q * KP + col] = static_cast<float>(t);
     }
@@ -972,7 +977,8 @@ extern "C" int sparc_lap_fwd(int64_t m, int64_t nnz, const int64_t* rowptr, cons
     if (kp == 16) { SPARC_SCALE(16) } else if (kp == 32) { SPARC_SCALE(32) } else if (kp == 48) { SPARC_SCALE(48) } else { SPARC_SCALE(64) }
 #undef SPARC_SCALE
     SPARC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(lap_colsum_finish, dim3(1), dim3(6 * kp), 0, stream, kp, static_cast<int>(p.nscale), dual,
+    const int split = min(FINISH_SPLIT, 1024 / (6 * kp));
+    hipLaunchKernelGGL(lap_colsum_finish, dim3(1), dim3(split * 6 * kp), 0, stream, kp, static_cast<int>(p.nscale), split, dual,
                        colpart, coupling, M12);
     SPARC_CHECK_LAUNCH();
 
