@@ -78,9 +78,15 @@ def inner_pass_bytes(b, k):
     own-row operand, result) -- at the real k for the algorithmic figure, at the kernel's column padding for
     the bytes it actually moves."""
     entry = b.nnz * (4 + 4 + (4 if b.valT is not None else 0)) + (b.m + 1) * 8
-    t = b.tiling(k, True)
-    kp = t.kp if t is not None else (16 if k <= 16 else 32 if k <= 32 else 64)
-    return entry + 3 * b.m * 2 * k * 4, entry + 3 * b.m * 2 * kp * 4
+    path = b.pass_kernel(k, True)
+    kp = b.tiling(k, True).kp if path == "tiles" else (16 if k <= 16 else 32 if k <= 32 else 64)
+    moved = entry + 3 * b.m * 2 * kp * 4
+    if path == "blocks":   # the blocks as dense arrays, the other entries as CSR, and the intermediate result written and re-read
+        bl = b.blocks(k, True)
+        per = 4 + 4 + (4 if b.valT is not None else 0)
+        n_blk = sum(int(d[2]) * 32 for d in bl["keep"][0].cpu().numpy()) * (2 if b.valT is not None else 1)
+        moved = n_blk * 4 + bl["r_nnz"] * per + (b.m + 1) * 8 + 5 * b.m * 2 * kp * 4
+    return entry + 3 * b.m * 2 * k * 4, moved
 
 
 def recorded_traffic(workload, b, k):
@@ -266,8 +272,11 @@ def main():
         per_launch = alg_bytes / max(2 * args.steps, 1)
         achieved = per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         b0 = trainer.batches[0]
-        t0_ = b0.tiling(k, True)
-        kernel = (f"spmm_win<vec {t0_.vec}, dual, add-x0> (kp {t0_.kp})" if t0_ is not None else "spmm_rows<dual, add-x0> (kp 64)") + \
+        path = b0.pass_kernel(k, True)
+        t0_ = b0.tiling(k, True) if path == "tiles" else None
+        kernel = (f"spmm_win<vec {t0_.vec}, dual, add-x0> (kp {t0_.kp})" if path == "tiles" else
+                  "dense_blocks<add-x0> (matrix cores, the clusters' diagonal blocks) + spmm_rows<dual, add-x0> on the other entries (kp 64)"
+                  if path == "blocks" else "spmm_rows<dual, add-x0> (kp 64)") + \
             ": the two inner passes of the Laplacian chain"
         out = {
             "metric": "SpectralNet train nodes/sec + SpMM HBM GB/s (% roofline), Amazon2M shape",

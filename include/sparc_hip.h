@@ -142,6 +142,39 @@ int sparc_lap_fwd(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* 
                   const sparc_tiling_t* tiling,
                   void* ws, size_t ws_bytes, sparc_stream_t stream);
 
+/* Dense diagonal blocks (optional; for batches whose clusters are small, nearly complete sub-graphs).
+ * The matrix is split as A = blockdiag(D_c) + C: cluster c is rows/columns [first, first + n) of the batch,
+ * D_c its n x n block padded with zeros to P x P (P = n rounded up to 32), and C the entries that join
+ * different clusters.  blk (device float32) holds the blocks stripe by stripe in k-major order: entry
+ * (i, j) of block c sits at offset_c + (i / 32) * (32 P) + j * 32 + i % 32; blkT holds the blocks of the
+ * mirrored values A[j, i] in the same layout (NULL or == blk for a numerically symmetric matrix).
+ * desc (device int32[ndesc][8]) = one record per (cluster, stripe of 32 rows):
+ * {first, n, P, stripe, offset_c & 0x7fffffff, offset_c >> 31, 0, 0}; max_p = the largest P.  The operand
+ * width W = 2 kp (training) or kp (forward only) must be a multiple of 32, kp a multiple of 32 when blkT
+ * is used, and (max_p W + 32 max_p (2 with blkT, else 1)) * 4 bytes must fit 152 KiB of LDS.
+ * sparc_lap_fwd_blocks is sparc_lap_fwd on that split: rowptr / colidx / val / valT describe C only
+ * (rows of C may be empty), every pass multiplies the blocks on the matrix cores
+ * (v_mfma_f32_32x32x2_f32) and the row kernel adds the gathers of C.  Reference semantics as sparc_lap_fwd
+ * (src/SpectralTrainer.py:116-139, :284-293). */
+typedef struct sparc_blocks {
+    const int32_t* desc; /* device */
+    int32_t ndesc;
+    int32_t max_p;
+    const float* blk;    /* device */
+    const float* blkT;   /* device or NULL */
+} sparc_blocks_t;
+
+int sparc_lap_fwd_blocks(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* colidx,
+                         const float* val, const float* valT, const float* rowc, const double* coupling,
+                         int k, int64_t ldy, const float* Y, double* loss, float* gradY,
+                         const sparc_blocks_t* blocks,
+                         void* ws, size_t ws_bytes, sparc_stream_t stream);
+
+/* Z = blockdiag(D_c) X (+ X0 if X0 != NULL), X, X0, Z [m][width], width a multiple of 32 up to 128:
+ * the dense-block part of a product on its own (tests and measurements). */
+int sparc_blocks_spmm(int64_t m, int width, const sparc_blocks_t* blocks, const float* X, const float* X0,
+                      float* Z, sparc_stream_t stream);
+
 /* Plain product Z = A X (+ X0 if X0 != NULL) on the same kernels, X, X0, Z [m][width] with
  * width in {16, 32, 64, 128}; pass the mirrored values as `val` for A^T X.  With a tiling
  * (dual = 0, kp = width = 16 vec: one slab, which is the row-major operand itself) the windowed

@@ -26,6 +26,11 @@ class Tiling(ctypes.Structure):
                 ("o_row", c_void_p), ("o_val", c_void_p), ("o_valT", c_void_p)]
 
 
+class Blocks(ctypes.Structure):
+    """sparc_blocks_t of include/sparc_hip.h: a host struct describing the dense diagonal blocks of a batch."""
+    _fields_ = [("desc", c_void_p), ("ndesc", c_int32), ("max_p", c_int32), ("blk", c_void_p), ("blkT", c_void_p)]
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise SparcHipError(
@@ -46,6 +51,8 @@ _SIGS = {
     "sparc_lap_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "sparc_lap_fwd": (c_int, [c_int64, c_int64, P, P, P, P, P, P, c_int, c_int64, P, P, P, P, P, c_size_t, P]),
     "sparc_spmm": (c_int, [c_int64, c_int64, P, P, P, c_int, P, P, P, P, P]),
+    "sparc_lap_fwd_blocks": (c_int, [c_int64, c_int64, P, P, P, P, P, P, c_int, c_int64, P, P, P, P, P, c_size_t, P]),
+    "sparc_blocks_spmm": (c_int, [c_int64, c_int, P, P, P, P, P]),
     "sparc_profile_begin": (c_int, [c_int, c_int]),
     "sparc_profile_end": (c_int, [P, P]),
     "sparc_gram_workspace_bytes": (c_size_t, [c_int64, c_int]),

@@ -22,6 +22,7 @@ struct SpmmArgs {
     const float* Xg;  // gathered operand  [m][W]
     const float* X0;  // own-row operand   [m][W]
     float* out;       // [m][W]
+    const float* addend;  // row kernel: [m][W] added to the row's product before the epilogue (the dense-block part), or null
     // Laplacian epilogues
     const float* rowc;  // [m][SPARC_ROWC]
     const float* M12;   // [6][KP]
@@ -57,6 +58,23 @@ struct SpmmArgs {
 
 // LDS budget of one window
 #define SPARC_TILE_LDS_BYTES (128 * 1024)
+
+// Dense diagonal blocks (blocks.hip): out = blockdiag(D_c) Xg (+ X0) on row-major [m][W] operands
+struct BlocksArgs {
+    const int32_t* desc;  // int32[ndesc][8]: {first row of the cluster, cluster rows, P, stripe, offset low 31 bits, offset high bits, 0, 0}
+    int ndesc;
+    int max_p;            // largest P
+    const float* blk;     // the blocks, stripe by stripe in k-major order (layout: include/sparc_hip.h)
+    const float* blkT;    // blocks of the mirrored values (== blk for a symmetric matrix or a forward-only pass)
+    const float* Xg;
+    const float* X0;
+    float* out;
+    int W;                // operand width, a multiple of 32 up to 128
+    int split;            // first column of the A^T half (W when there is none)
+};
+#define SPARC_BLOCKS_LDS_BYTES (152 * 1024)
+size_t sparc_blocks_lds_bytes(int max_p, int W, bool mirrored);
+int sparc_blocks_launch(const BlocksArgs& a, bool add, hipStream_t stream);
 
 int sparc_spmm_launch(int epi, int width, const SpmmArgs& a, hipStream_t stream);
 int64_t sparc_rows_blocks(int64_t m);

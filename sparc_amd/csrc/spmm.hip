@@ -241,6 +241,10 @@ __device__ __forceinline__ void wave_row_global(const SpmmArgs& a, const int64_t
     const bool right = DUAL && lr >= HALF;
     const int cl = (DUAL ? (lr % HALF) : lr) * 4;
     const LapConst<4> lc = lap_const<4, EPI>(a, cl, right);
+    if (a.addend) {  // the part of the row's product that another kernel has formed (dense diagonal blocks)
+        const float4 t = *reinterpret_cast<const float4*>(a.addend + row * W + lr * 4);
+        acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+    }
     float accv[4] = {acc.x, acc.y, acc.z, acc.w};
     row_epilogue<4, DUAL, EPI>(a, row, lane, g == 0, HALF, cl, right, pre, lc, accv,
                                a.out ? a.out + row * W + lr * 4 : nullptr, a.col0 + lr * 4, wloss);
@@ -931,10 +935,13 @@ extern "C" size_t sparc_lap_workspace_bytes(int64_t m, int k, int ntiles) {
     return lap_plan(m, SPARC_MAX_K, ntiles).bytes;   // covers the column padding of every kernel variant
 }
 
-extern "C" int sparc_lap_fwd(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* colidx, const float* val,
-                             const float* valT, const float* rowc, const double* coupling, int k, int64_t ldy,
-                             const float* Y, double* loss, float* gradY, const sparc_tiling_t* tiling,
-                             void* ws, size_t ws_bytes, sparc_stream_t stream) {
+namespace {
+// The Laplacian pass on the row kernel (tiling == blocks == NULL), the windowed kernel (tiling) or dense
+// diagonal blocks plus the row kernel on the remaining entries (blocks; the CSR arrays then hold only those).
+int lap_fwd_impl(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* colidx, const float* val,
+                 const float* valT, const float* rowc, const double* coupling, int k, int64_t ldy,
+                 const float* Y, double* loss, float* gradY, const sparc_tiling_t* tiling, const sparc_blocks_t* blocks,
+                 void* ws, size_t ws_bytes, hipStream_t stream) {
     if (m <= 0 || nnz < 0 || k < 1 || k > SPARC_MAX_K || ldy < k || !rowptr || !rowc || !coupling || !Y || !loss ||
         (nnz > 0 && (!colidx || !val)))
         return SPARC_ERR_ARG;
@@ -942,6 +949,17 @@ extern "C" int sparc_lap_fwd(int64_t m, int64_t nnz, const int64_t* rowptr, cons
     const bool tiled = tiling != nullptr;
     const int kp = tiled ? tiling->kp : padded_k(k, false);
     if (kp < k || kp > SPARC_MAX_K || kp % 16) return SPARC_ERR_ARG;
+    BlocksArgs bl = {};
+    if (blocks) {
+        const int Wb = dual ? 2 * kp : kp;
+        const bool mirrored = dual && blocks->blkT && blocks->blkT != blocks->blk;
+        if (tiled || !blocks->desc || blocks->ndesc <= 0 || !blocks->blk || Wb % 32 || (mirrored && kp % 32) ||
+            blocks->max_p < 32 || blocks->max_p % 32 || sparc_blocks_lds_bytes(blocks->max_p, Wb, mirrored) > SPARC_BLOCKS_LDS_BYTES)
+            return SPARC_ERR_ARG;
+        bl.desc = blocks->desc; bl.ndesc = blocks->ndesc; bl.max_p = blocks->max_p;
+        bl.blk = blocks->blk; bl.blkT = mirrored ? blocks->blkT : blocks->blk;
+        bl.W = Wb; bl.split = dual ? kp : Wb;
+    }
     const LapPlan p = lap_plan(m, kp, tiled ? tiling->ndesc : 0);
     if (p.bytes > sparc_lap_workspace_bytes(m, k, tiled ? tiling->ndesc : 0)) return SPARC_ERR_ARG;
     WsCarver c(ws, ws_bytes);
@@ -983,23 +1001,67 @@ extern "C" int sparc_lap_fwd(int64_t m, int64_t nnz, const int64_t* rowptr, cons
     SPARC_CHECK_LAUNCH();
 
     a.X0 = X;
-    // Horner: chain(X) = A (X + A (X + A X))
+    // Horner: chain(X) = A (X + A (X + A X)).  With dense blocks a pass is two launches: the blocks' product
+    // (plus the own-row operand), then the row kernel over the remaining entries, which adds its gathers to it.
     {
         Timed both(EPI_ADD_X0, stream, 2);   // the two inner passes, back to back
         a.Xg = X; a.out = P1;
+        if (blocks) {
+            bl.Xg = X; bl.X0 = X; bl.out = P1;
+            if ((rcode = sparc_blocks_launch(bl, true, stream))) return rcode;
+            a.X0 = P1;   // each lane reads and rewrites its own elements only
+        }
         rcode = dual ? launch_dual<EPI_ADD_X0>(kp, a, stream) : launch_single<EPI_ADD_X0>(W, a, stream);
         if (rcode) return rcode;
         a.Xg = P1; a.out = P2;
+        if (blocks) {
+            bl.Xg = P1; bl.X0 = X; bl.out = P2;
+            if ((rcode = sparc_blocks_launch(bl, true, stream))) return rcode;
+            a.X0 = P2;
+        }
         rcode = dual ? launch_dual<EPI_ADD_X0>(kp, a, stream) : launch_single<EPI_ADD_X0>(W, a, stream);
         if (rcode) return rcode;
     }
-    a.Xg = P2; a.out = nullptr;
+    a.Xg = P2; a.out = nullptr; a.X0 = X;
     {
         Timed last(dual ? EPI_LAP_DUAL : EPI_LAP_SINGLE, stream, 1);
+        if (blocks) {
+            bl.Xg = P2; bl.X0 = nullptr; bl.out = P1;   // P1 is free again
+            if ((rcode = sparc_blocks_launch(bl, false, stream))) return rcode;
+            a.addend = P1;
+        }
         rcode = dual ? launch_dual<EPI_LAP_DUAL>(kp, a, stream) : launch_single<EPI_LAP_SINGLE>(W, a, stream);
         if (rcode) return rcode;
     }
     hipLaunchKernelGGL(loss_finish, dim3(1), dim3(256), 0, stream, nparts, loss_part, 1.0 / static_cast<double>(m), loss);
     SPARC_CHECK_LAUNCH();
     return SPARC_OK;
+}
+}  // namespace
+
+extern "C" int sparc_lap_fwd(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* colidx, const float* val,
+                             const float* valT, const float* rowc, const double* coupling, int k, int64_t ldy,
+                             const float* Y, double* loss, float* gradY, const sparc_tiling_t* tiling,
+                             void* ws, size_t ws_bytes, sparc_stream_t stream) {
+    return lap_fwd_impl(m, nnz, rowptr, colidx, val, valT, rowc, coupling, k, ldy, Y, loss, gradY, tiling, nullptr, ws, ws_bytes,
+                        stream);
+}
+
+extern "C" int sparc_lap_fwd_blocks(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* colidx, const float* val,
+                                    const float* valT, const float* rowc, const double* coupling, int k, int64_t ldy,
+                                    const float* Y, double* loss, float* gradY, const sparc_blocks_t* blocks,
+                                    void* ws, size_t ws_bytes, sparc_stream_t stream) {
+    if (!blocks) return SPARC_ERR_ARG;
+    return lap_fwd_impl(m, nnz, rowptr, colidx, val, valT, rowc, coupling, k, ldy, Y, loss, gradY, nullptr, blocks, ws, ws_bytes,
+                        stream);
+}
+
+extern "C" int sparc_blocks_spmm(int64_t m, int width, const sparc_blocks_t* blocks, const float* X, const float* X0, float* Z,
+                                 sparc_stream_t stream) {
+    if (m <= 0 || !blocks || !blocks->desc || !blocks->blk || !X || !Z || width % 32 || width < 32 || width > 128) return SPARC_ERR_ARG;
+    BlocksArgs bl = {};
+    bl.desc = blocks->desc; bl.ndesc = blocks->ndesc; bl.max_p = blocks->max_p;
+    bl.blk = blocks->blk; bl.blkT = blocks->blk;
+    bl.Xg = X; bl.X0 = X0; bl.out = Z; bl.W = width; bl.split = width;
+    return sparc_blocks_launch(bl, X0 != nullptr, stream);
 }

@@ -256,6 +256,7 @@ class ClusterBatch:
         self.device = device
         self._windows = plan_windows(m, cluster_sizes)
         self._tiles = {}
+        self._blocks = None
         self._measured = {}
         self._window_ranges = None
         self._prepare(eps)
@@ -309,7 +310,7 @@ class ClusterBatch:
         k, too large a share of the batch's entries outside the windows, or the row kernel measured faster
         (warm(measure=True))."""
         geo = self.tile_geometry(k, training)
-        if geo is None or self._measured.get((k, bool(training))) == "rows":
+        if geo is None or self._measured.get((k, bool(training))) in ("rows", "blocks"):
             return None
         vec, kp, n_slabs = geo
         threads = self.tile_threads or (512 if vec == 2 else 1024)
@@ -318,6 +319,82 @@ class ClusterBatch:
         if key not in self._tiles:
             self._tiles[key] = self._plan(vec, kp, n_slabs, bool(training), threads, target)
         return self._tiles[key]
+
+    # ---- dense diagonal blocks ------------------------------------------------------------------
+    # Batches whose clusters are small, nearly complete sub-graphs (Reddit shape: 155-node clusters, 86 % of the
+    # node pairs connected) multiply their diagonal blocks on the matrix cores; the row kernel adds the entries
+    # that join different clusters.  Below this fill a gather moves fewer bytes than the dense block.
+    block_min_fill = 0.35
+    block_max_rows = 192          # P x W floats of operand + the block stripes must fit 152 KiB of LDS at W = 128
+    use_blocks = True
+
+    def blocks(self, k: int, training: bool):
+        """(_lib.Blocks, remainder CSR tensors) of this batch for the given pass, or None: no cluster sizes,
+        clusters too large or too sparse, or an operand width the block kernel does not take."""
+        kp = 16 if k <= 16 else 32 if k <= 32 else 64      # the row kernel's column padding
+        W = 2 * kp if training else kp
+        if not self.use_blocks or W % 32 or self.nnz == 0:
+            return None
+        if self._blocks is None:
+            self._blocks = self._plan_blocks() or False
+        if self._blocks is False:
+            return None
+        bl = self._blocks
+        mirrored = training and self.valT is not None
+        if mirrored and kp % 32:
+            return None
+        lds = (bl["max_p"] * W + (2 if mirrored else 1) * bl["max_p"] * 32) * 4
+        return bl if lds <= 152 * 1024 else None
+
+    def _plan_blocks(self):
+        sizes = self.cluster_sizes
+        if sizes is None or int(np.sum(sizes)) != self.m:
+            return None
+        sizes = np.asarray([int(x) for x in sizes if int(x) > 0], dtype=np.int64)
+        if len(sizes) == 0 or sizes.max() > self.block_max_rows:
+            return None
+        dev, m = self.device, self.m
+        start = np.concatenate([[0], np.cumsum(sizes)])
+        cl_of = torch.from_numpy(np.repeat(np.arange(len(sizes)), sizes)).to(dev)
+        counts = self.rowptr[1:] - self.rowptr[:-1]
+        row = torch.repeat_interleave(torch.arange(m, device=dev), counts)
+        col = self.colidx.to(torch.int64)
+        same = cl_of[row] == cl_of[col]
+        fill = float(same.sum()) / float((sizes.astype(np.float64) ** 2).sum())
+        if fill < self.block_min_fill:
+            return None
+        P = (sizes + 31) // 32 * 32
+        off = np.concatenate([[0], np.cumsum(P * P)])
+        if off[-1] >= 2 ** 40:
+            return None
+        desc = []
+        for c in range(len(sizes)):
+            for st in range(int(P[c]) // 32):
+                if st * 32 < sizes[c]:
+                    desc.append((start[c], sizes[c], P[c], st, off[c] & 0x7fffffff, off[c] >> 31, 0, 0))
+        desc_d = torch.from_numpy(np.asarray(desc, dtype=np.int32)).to(dev)
+        start_d, P_d, off_d = (torch.from_numpy(x.astype(np.int64)).to(dev) for x in (start[:-1], P, off[:-1]))
+        r_in, c_in = row[same], col[same]
+        cl = cl_of[r_in]
+        i, j = r_in - start_d[cl], c_in - start_d[cl]
+        pos = off_d[cl] + torch.div(i, 32, rounding_mode="floor") * (32 * P_d[cl]) + j * 32 + i % 32
+        blk = torch.zeros(int(off[-1]), dtype=torch.float32, device=dev)
+        blk[pos] = self.val[same]
+        blkT = None
+        if self.valT is not None:
+            blkT = torch.zeros_like(blk)
+            blkT[pos] = self.valT[same]
+        # the remaining entries as CSR
+        rest = ~same
+        r_rowptr = torch.zeros(m + 1, dtype=torch.int64, device=dev)
+        r_rowptr[1:] = torch.cumsum(torch.bincount(row[rest], minlength=m), 0)
+        r_col = self.colidx[rest].contiguous()
+        r_val = self.val[rest].contiguous()
+        r_valT = self.valT[rest].contiguous() if self.valT is not None else None
+        b = _lib.Blocks(desc_d.data_ptr(), int(desc_d.shape[0]), int(P.max()), blk.data_ptr(),
+                        blkT.data_ptr() if blkT is not None else None)
+        return {"struct": b, "keep": (desc_d, blk, blkT), "max_p": int(P.max()), "fill": fill, "ndesc": int(desc_d.shape[0]),
+                "r_rowptr": r_rowptr, "r_col": r_col, "r_val": r_val, "r_valT": r_valT, "r_nnz": int(rest.sum())}
 
     def _plan(self, vec, kp, n_slabs, dual, threads, target, mirrored=False):
         """Tiling for one kernel geometry: work descriptors and slot records (planned on the host) and the
@@ -408,10 +485,12 @@ class ClusterBatch:
         the batch has a tiling, time its pass on both kernels (reps calls each, about a millisecond in all) and
         keep the faster one for this (k, training); both produce the same result to rounding, so the choice
         only moves time."""
-        if self.tiling(k, training) is not None and measure and (k, bool(training)) not in self._measured:
+        names = [n for n, ok in (("blocks", self.blocks(k, training) is not None), ("tiles", self.tiling(k, training) is not None),
+                                 ("rows", True)) if ok]
+        if len(names) > 1 and measure and (k, bool(training)) not in self._measured:
             Y = torch.randn(self.m, k, device=self.device)
             took = {}
-            for name in ("tiles", "rows"):
+            for name in names:
                 self._measured[(k, bool(training))] = name
                 self.lap(Y, training)
                 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
@@ -441,7 +520,9 @@ class ClusterBatch:
             Y = Y.float().contiguous()
         loss = torch.empty((), dtype=torch.float64, device=self.device)
         grad = torch.empty_like(Y) if want_grad else None
-        t = self.tiling(k, want_grad)
+        choice = self._measured.get((k, bool(want_grad)))
+        bl = self.blocks(k, want_grad) if choice in (None, "blocks") else None
+        t = self.tiling(k, want_grad) if bl is None else None
         nbytes = lib.sparc_lap_workspace_bytes(self.m, k, t.ndesc if t is not None else 0)
         ws = Workspace.get(nbytes, self.device)
         with torch.cuda.device(self.device):
@@ -451,6 +532,12 @@ class ClusterBatch:
                     self._rowc_plain = self.rowc.clone()
                     self._rowc_plain[:, 3] = 1.0
                 rowc = self._rowc_plain
+            if bl is not None:
+                check(lib.sparc_lap_fwd_blocks(self.m, bl["r_nnz"], _ptr(bl["r_rowptr"]), _ptr(bl["r_col"]), _ptr(bl["r_val"]),
+                                               _ptr(bl["r_valT"]), _ptr(rowc), _ptr(self.coupling), k, k, _ptr(Y), _ptr(loss),
+                                               _ptr(grad), ctypes.byref(bl["struct"]), _ptr(ws), nbytes, _stream()),
+                      "sparc_lap_fwd_blocks")
+                return loss, grad
             check(lib.sparc_lap_fwd(self.m, self.nnz, _ptr(self.rowptr), _ptr(self.colidx), _ptr(self.val),
                                     _ptr(self.valT), _ptr(rowc), _ptr(self.coupling), k, k, _ptr(Y), _ptr(loss),
                                     _ptr(grad), ctypes.byref(t) if t is not None else None, _ptr(ws), nbytes, _stream()),
@@ -482,6 +569,28 @@ class ClusterBatch:
                                  _ptr(X), _ptr(add), _ptr(Z), ctypes.byref(t) if t is not None else None, _stream()),
                   "sparc_spmm")
         return Z
+
+    def block_spmm(self, X: torch.Tensor, add: torch.Tensor | None = None) -> torch.Tensor:
+        """Z = blockdiag(D_c) X (+ add): the dense-block part of the product alone (tests and measurements);
+        width of X a multiple of 32 up to 128."""
+        bl = self.blocks(int(X.shape[1]), False) if int(X.shape[1]) in (32, 64) else None
+        if self._blocks in (None, False):
+            raise ValueError("this batch has no dense blocks")
+        bl = self._blocks
+        X = X.contiguous()
+        Z = torch.zeros_like(X)
+        with torch.cuda.device(self.device):
+            check(lib.sparc_blocks_spmm(self.m, int(X.shape[1]), ctypes.byref(bl["struct"]), _ptr(X), _ptr(add), _ptr(Z), _stream()),
+                  "sparc_blocks_spmm")
+        return Z
+
+    def pass_kernel(self, k: int, training: bool = True) -> str:
+        """Which kernels lap() runs for this (k, training): "blocks" (dense diagonal blocks + row kernel on the
+        rest), "tiles" (windowed kernel) or "rows"."""
+        choice = self._measured.get((k, bool(training)))
+        if choice in (None, "blocks") and self.blocks(k, training) is not None:
+            return "blocks"
+        return "tiles" if self.tiling(k, training) is not None else "rows"
 
     def nbytes(self) -> int:
         t = [self.rowptr, self.colidx, self.val, self.rowc, self.d, self.cw, self.rho]

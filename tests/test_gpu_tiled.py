@@ -235,6 +235,7 @@ def test_full_size_batch_tiled_equals_row_kernel(dev, workload, min_m, min_nnz, 
     from sparc_amd.graph import ClusterBatch
     from sparc_amd import synth
     monkeypatch.setattr(ClusterBatch, "tile_max_outside_share", 1.0)   # Reddit's share is above the planner's limit
+    monkeypatch.setattr(ClusterBatch, "use_blocks", False)             # ... and its clusters would run as dense blocks
     b, k = synth.shape_batch(workload, dev)
     assert b.m >= min_m and b.nnz >= min_nnz, (b.m, b.nnz)
     cen = tiling_census(b, k, True)

@@ -29,6 +29,19 @@ print(f"{workload}: m={b.m} nnz={b.nnz} k={k} windows={len(b._windows)} entries 
       + (f"vec={t.vec} kp={t.kp} threads={t.threads} descriptors={t.ndesc} rows={t.rows}" if t else "none"), flush=True)
 Y = torch.randn(b.m, k, device=dev)
 reps = int(os.environ.get("REPS", "20"))
+if b.blocks(k, True) is not None:
+    bl = b.blocks(k, True)
+    print("dense blocks:", "none" if bl is None else f"fill {bl['fill']:.3f}, {bl['ndesc']} workgroups, {bl['r_nnz']} entries left to the row kernel", flush=True)
+    for _ in range(3):
+        b.lap(Y, True)
+        b.lap(Y, False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        b.lap(Y, True)
+    torch.cuda.synchronize()
+    print(f"blocks lap_fwd(dual) {1e6 * (time.perf_counter() - t0) / reps:.1f} us/call", flush=True)
+ClusterBatch.use_blocks = False
 for tiles in (True, False):
     ClusterBatch.use_tiles = tiles
     for _ in range(3):
