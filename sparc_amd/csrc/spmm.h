@@ -71,10 +71,17 @@ struct BlocksArgs {
     float* out;
     int W;                // operand width, a multiple of 32 up to 128
     int split;            // first column of the A^T half (W when there is none)
+    // fused launch: the entries outside the blocks, CSR (r_valT == r_val for symmetric values)
+    const int64_t* r_rowptr;
+    const int32_t* r_col;
+    const float* r_val;
+    const float* r_valT;
+    int dbg;              // ablation switches for kernel timing experiments (0 in production)
 };
 #define SPARC_BLOCKS_LDS_BYTES (152 * 1024)
-size_t sparc_blocks_lds_bytes(int max_p, int W, bool mirrored);
-int sparc_blocks_launch(const BlocksArgs& a, bool add, hipStream_t stream);
+size_t sparc_blocks_lds_bytes(int max_p, int W, bool mirrored, bool fused);
+bool sparc_blocks_can_fuse(int max_p, int W, bool mirrored);
+int sparc_blocks_launch(const BlocksArgs& a, bool add, bool fused, hipStream_t stream);
 
 int sparc_spmm_launch(int epi, int width, const SpmmArgs& a, hipStream_t stream);
 int64_t sparc_rows_blocks(int64_t m);

@@ -950,15 +950,18 @@ int lap_fwd_impl(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* c
     const int kp = tiled ? tiling->kp : padded_k(k, false);
     if (kp < k || kp > SPARC_MAX_K || kp % 16) return SPARC_ERR_ARG;
     BlocksArgs bl = {};
+    bool fuse = false;   // the inner passes gather the entries outside the blocks in the block kernel's own launch
     if (blocks) {
         const int Wb = dual ? 2 * kp : kp;
         const bool mirrored = dual && blocks->blkT && blocks->blkT != blocks->blk;
         if (tiled || !blocks->desc || blocks->ndesc <= 0 || !blocks->blk || Wb % 32 || (mirrored && kp % 32) ||
-            blocks->max_p < 32 || blocks->max_p % 32 || sparc_blocks_lds_bytes(blocks->max_p, Wb, mirrored) > SPARC_BLOCKS_LDS_BYTES)
+            blocks->max_p < 32 || blocks->max_p % 32 || sparc_blocks_lds_bytes(blocks->max_p, Wb, mirrored, false) > SPARC_BLOCKS_LDS_BYTES)
             return SPARC_ERR_ARG;
         bl.desc = blocks->desc; bl.ndesc = blocks->ndesc; bl.max_p = blocks->max_p;
         bl.blk = blocks->blk; bl.blkT = mirrored ? blocks->blkT : blocks->blk;
         bl.W = Wb; bl.split = dual ? kp : Wb;
+        bl.r_rowptr = rowptr; bl.r_col = colidx; bl.r_val = val; bl.r_valT = (dual && valT) ? valT : val;
+        fuse = sparc_blocks_can_fuse(blocks->max_p, Wb, mirrored);
     }
     const LapPlan p = lap_plan(m, kp, tiled ? tiling->ndesc : 0);
     if (p.bytes > sparc_lap_workspace_bytes(m, k, tiled ? tiling->ndesc : 0)) return SPARC_ERR_ARG;
@@ -1008,26 +1011,30 @@ int lap_fwd_impl(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* c
         a.Xg = X; a.out = P1;
         if (blocks) {
             bl.Xg = X; bl.X0 = X; bl.out = P1;
-            if ((rcode = sparc_blocks_launch(bl, true, stream))) return rcode;
+            if ((rcode = sparc_blocks_launch(bl, true, fuse, stream))) return rcode;
             a.X0 = P1;   // each lane reads and rewrites its own elements only
         }
-        rcode = dual ? launch_dual<EPI_ADD_X0>(kp, a, stream) : launch_single<EPI_ADD_X0>(W, a, stream);
-        if (rcode) return rcode;
+        if (!fuse) {
+            rcode = dual ? launch_dual<EPI_ADD_X0>(kp, a, stream) : launch_single<EPI_ADD_X0>(W, a, stream);
+            if (rcode) return rcode;
+        }
         a.Xg = P1; a.out = P2;
         if (blocks) {
             bl.Xg = P1; bl.X0 = X; bl.out = P2;
-            if ((rcode = sparc_blocks_launch(bl, true, stream))) return rcode;
+            if ((rcode = sparc_blocks_launch(bl, true, fuse, stream))) return rcode;
             a.X0 = P2;
         }
-        rcode = dual ? launch_dual<EPI_ADD_X0>(kp, a, stream) : launch_single<EPI_ADD_X0>(W, a, stream);
-        if (rcode) return rcode;
+        if (!fuse) {
+            rcode = dual ? launch_dual<EPI_ADD_X0>(kp, a, stream) : launch_single<EPI_ADD_X0>(W, a, stream);
+            if (rcode) return rcode;
+        }
     }
     a.Xg = P2; a.out = nullptr; a.X0 = X;
     {
         Timed last(dual ? EPI_LAP_DUAL : EPI_LAP_SINGLE, stream, 1);
         if (blocks) {
             bl.Xg = P2; bl.X0 = nullptr; bl.out = P1;   // P1 is free again
-            if ((rcode = sparc_blocks_launch(bl, false, stream))) return rcode;
+            if ((rcode = sparc_blocks_launch(bl, false, false, stream))) return rcode;
             a.addend = P1;
         }
         rcode = dual ? launch_dual<EPI_LAP_DUAL>(kp, a, stream) : launch_single<EPI_LAP_SINGLE>(W, a, stream);
@@ -1063,5 +1070,5 @@ extern "C" int sparc_blocks_spmm(int64_t m, int width, const sparc_blocks_t* blo
     bl.desc = blocks->desc; bl.ndesc = blocks->ndesc; bl.max_p = blocks->max_p;
     bl.blk = blocks->blk; bl.blkT = blocks->blk;
     bl.Xg = X; bl.X0 = X0; bl.out = Z; bl.W = width; bl.split = width;
-    return sparc_blocks_launch(bl, X0 != nullptr, stream);
+    return sparc_blocks_launch(bl, X0 != nullptr, false, stream);
 }
