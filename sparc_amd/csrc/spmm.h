@@ -23,6 +23,7 @@ struct SpmmArgs {
     const float* X0;  // own-row operand   [m][W]
     float* out;       // [m][W]
     const float* addend;  // row kernel: [m][W] added to the row's product before the epilogue (the dense-block part), or null
+    int skip_entries;     // row kernel: the addend is the whole product, no entry is gathered (epilogue only)
     // Laplacian epilogues
     const float* rowc;  // [m][SPARC_ROWC]
     const float* M12;   // [6][KP]

@@ -208,7 +208,7 @@ __device__ __forceinline__ void wave_row_global(const SpmmArgs& a, const int64_t
     constexpr int G = 64 / LR;      // rows of X gathered per wave instruction
     constexpr int HALF = LR / 2;
     const int g = lane / LR, lr = lane % LR;
-    const int64_t p0 = a.rowptr[row], p1 = a.rowptr[row + 1];
+    const int64_t p0 = a.skip_entries ? 0 : a.rowptr[row], p1 = a.skip_entries ? 0 : a.rowptr[row + 1];
     const RowPre<4> pre = row_preload<4, EPI>(a, row, a.X0 ? a.X0 + row * W + lr * 4 : nullptr);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int64_t p = p0; p < p1; p += 64) {
@@ -1034,8 +1034,9 @@ int lap_fwd_impl(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* c
         Timed last(dual ? EPI_LAP_DUAL : EPI_LAP_SINGLE, stream, 1);
         if (blocks) {
             bl.Xg = P2; bl.X0 = nullptr; bl.out = P1;   // P1 is free again
-            if ((rcode = sparc_blocks_launch(bl, false, false, stream))) return rcode;
+            if ((rcode = sparc_blocks_launch(bl, false, fuse, stream))) return rcode;
             a.addend = P1;
+            a.skip_entries = fuse ? 1 : 0;   // fused: P1 is the whole product, the row kernel only runs its epilogue
         }
         rcode = dual ? launch_dual<EPI_LAP_DUAL>(kp, a, stream) : launch_single<EPI_LAP_SINGLE>(W, a, stream);
         if (rcode) return rcode;
