@@ -276,7 +276,7 @@ def main():
         t0_ = b0.tiling(k, True) if path == "tiles" else None
         kernel = (f"spmm_win<vec {t0_.vec}, dual, add-x0> (kp {t0_.kp})" if path == "tiles" else
                   "dense_blocks<add-x0> (matrix cores, the clusters' diagonal blocks) + spmm_rows<dual, add-x0> on the other entries (kp 64)"
-                  if path == "blocks" else "spmm_rows<dual, add-x0> (kp 64)") + \
+                  if path == "blocks" else f"spmm_rows<dual, add-x0> (kp {16 if k <= 16 else 32 if k <= 32 else 64})") + \
             ": the two inner passes of the Laplacian chain"
         out = {
             "metric": "SpectralNet train nodes/sec + SpMM HBM GB/s (% roofline), Amazon2M shape",
