@@ -100,3 +100,28 @@ def test_per_step_kernels_do_not_spill(spmm_asm):
         spills[m.group(1)] = int(m.group(2))
     assert len(spills) >= 16
     assert max(spills.values()) <= 8, {k: v for k, v in spills.items() if v > 8}
+
+
+def test_block_kernel_staging_and_registers(tmp_path):
+    """dense_blocks (blocks.hip): the asynchronous global->LDS staging is waited for (vmcnt(0)) before the first
+    synchronisation that publishes it (the barrier, or the staging counter of the fused variants), the matrix
+    instruction is the 32x32x2 f32 one, and no variant spills."""
+    from sparc_amd import build
+    out = tmp_path / "blocks.s"
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    flags = [f for f in build.FLAGS if f != "-fPIC"]
+    subprocess.run([hipcc] + flags + ["-S", "--cuda-device-only", "-o", str(out),
+                                      os.path.join(ROOT, "sparc_amd", "csrc", "blocks.hip")], check=True, cwd=str(tmp_path))
+    text = out.read_text()
+    found = 0
+    for m in re.finditer(r"^(_Z\w*dense_blocks\w*):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
+        ins = [l.split(";")[0].strip() for l in m.group(2).splitlines()]
+        ins = [l for l in ins if l and not l.startswith(".") and not l.endswith(":")]
+        found += 1
+        last_dma = max(i for i, l in enumerate(ins) if "global_load_lds" in l)
+        sync = next(i for i, l in enumerate(ins[last_dma:]) if l.startswith("s_barrier") or l.startswith("ds_add")) + last_dma
+        assert any(re.match(r"s_waitcnt vmcnt\(0\)", l) for l in ins[last_dma:sync]), m.group(1)
+        assert any("v_mfma_f32_32x32x2" in l for l in ins), m.group(1)
+    assert found == 4
+    spills = [int(x) for x in re.findall(r"\.name:\s+\S*dense_blocks\S*\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text)]
+    assert len(spills) == 4 and max(spills) == 0, spills
