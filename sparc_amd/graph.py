@@ -573,8 +573,9 @@ class ClusterBatch:
     def block_spmm(self, X: torch.Tensor, add: torch.Tensor | None = None) -> torch.Tensor:
         """Z = blockdiag(D_c) X (+ add): the dense-block part of the product alone (tests and measurements);
         width of X a multiple of 32 up to 128."""
-        bl = self.blocks(int(X.shape[1]), False) if int(X.shape[1]) in (32, 64) else None
-        if self._blocks in (None, False):
+        if self._blocks is None:
+            self._blocks = self._plan_blocks() or False
+        if self._blocks is False:
             raise ValueError("this batch has no dense blocks")
         bl = self._blocks
         X = X.contiguous()
