@@ -143,3 +143,21 @@ def test_reddit_shape_batch_blocks_equal_row_kernel(dev, monkeypatch):
     assert rel(lv.item(), loss_r.item()) < 1e-5
     inner = (grad.double() * Y.double()).sum().item()       # gradient of a quadratic form: <grad, Y> = 2 loss
     assert abs(inner - 2 * loss.item()) / loss.item() < 1e-4
+
+
+def test_block_diagonal_batch_without_other_entries(dev):
+    """A batch whose clusters are not connected at all: the CSR of the other entries is empty (every row)."""
+    from sparc_amd.graph import ClusterBatch
+    rng = np.random.default_rng(9)
+    sizes = [40, 64, 17]
+    D, _ = dense_cluster_graph(rng, sizes, cross_per_row=0.0)
+    s = make_support(D, "raw")
+    A, _ = O.csr_from_support(s)
+    k = 20
+    Y = rng.standard_normal((A.shape[0], k)).astype(np.float32)
+    loss_o, g_o, _, _ = O.lap_forward_operator(A, O.affinity_prep_operator(A), Y.astype(np.float64))
+    b = ClusterBatch.from_support(s, dev, cluster_sizes=sizes)
+    bl = b.blocks(k, True)
+    assert bl is not None and bl["r_nnz"] == 0
+    loss, grad = b.lap(torch.tensor(Y, device=dev), True)
+    assert rel(loss.item(), loss_o) < 1e-4 and rel(grad.cpu().numpy(), g_o) < 1e-4
