@@ -314,6 +314,19 @@ int sparc_subblock_fill(int64_t n, const int64_t* indptr, const int32_t* indices
 int sparc_row_rank_values(int64_t rows, int64_t n, const double* D, int64_t ld, int nranks,
                           const int64_t* ranks, double* out, sparc_stream_t stream);
 
+/* ---- graph partitioner: label scores of one propagation sweep -------------------------
+ * The partitioner stands in for metis.part_graph (src/partition_utils.py:56); this is the per-sweep
+ * kernel of its size-constrained label propagation.  Graph as CSR without self loops (rowptr int64[n+1],
+ * nbr int64[E] neighbour ids, w int64[E] positive edge weights), labels int64[n] in [0, n_labels).
+ * For every node: cur = total weight towards its own label; best / best_lab = the largest total
+ * towards one label and that label (ties: the smallest), taken over the labels with label_ok[l] != 0
+ * (uint8[n_labels]; NULL: all) and, with exclude_own, other than the node's own; best = 0 and
+ * best_lab = n_labels when there is none, and for a node whose neighbours carry more than 1024
+ * distinct labels (no proposal in this sweep). */
+int sparc_label_scores(int64_t n, const int64_t* rowptr, const int64_t* nbr, const int64_t* w,
+                       const int64_t* labels, int64_t n_labels, const uint8_t* label_ok, int exclude_own,
+                       int64_t* best, int64_t* best_lab, int64_t* cur, sparc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

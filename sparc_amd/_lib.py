@@ -71,6 +71,7 @@ _SIGS = {
     "sparc_dgrad_narrow_relu_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "sparc_dgrad_narrow_relu": (c_int, [c_int64, c_int, c_int, P, c_int64, P, P, c_int64, P, c_int64, P, P, c_size_t, P]),
     "sparc_row_rank_values": (c_int, [c_int64, c_int64, P, c_int64, c_int, P, P, P]),
+    "sparc_label_scores": (c_int, [c_int64, P, P, P, P, c_int64, P, c_int, P, P, P, P]),
     "sparc_subblock_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "sparc_subblock_count": (c_int, [c_int64, P, P, P, c_int64, P, c_int, P, P, P, c_size_t, P]),
     "sparc_subblock_fill": (c_int, [c_int64, P, P, P, c_int64, P, c_int, c_double, P, P, P, P, P, c_size_t, P]),

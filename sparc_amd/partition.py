@@ -10,9 +10,11 @@ node in one part, parts of near-equal size, few edges between parts.
 Method: multilevel size-constrained label propagation.  Coarsening sweeps merge every node into
 the neighbouring cluster it is connected to most strongly (subject to a size cap) and contract;
 the coarsest graph is packed into k parts; the way back up refines with the same sweep restricted
-to moves that reduce the cut and respect the part capacity.  A sweep is three sorts and a few
-segmented reductions over the edge list, all on the device that holds the graph (integer
-weights: results are deterministic).
+to moves that reduce the cut and respect the part capacity.  On the GPU the per-node label totals of a
+sweep come from one wavefront-per-node kernel over the CSR adjacency (sparc_label_scores); the choice of the
+moves that fit the capacities is a few sorts over the candidate nodes.  The same sweep is also written with
+sorts and segmented reductions over the edge list for any torch device (integer weights: results are
+deterministic and the two agree).
 """
 from __future__ import annotations
 
@@ -25,7 +27,25 @@ import torch
 
 
 # --------------------------------------------------------------------------- one propagation sweep
-def _sweep(labels, src, dst, w, nw, cap, n_labels, parity, evict_to=None, pull_to=None):
+def _label_scores_kernel(labels, rowptr, dst, w, n_labels, label_ok, exclude_own):
+    """(best, best_lab, cur) of every node from the wavefront-per-node kernel of libsparc_hip.so (sparc_label_scores)."""
+    import ctypes
+    from ._lib import check, lib
+    n = labels.numel()
+    dev = labels.device
+    best = torch.empty(n, dtype=torch.int64, device=dev)
+    best_lab = torch.empty(n, dtype=torch.int64, device=dev)
+    cur = torch.empty(n, dtype=torch.int64, device=dev)
+    ok = label_ok.to(torch.uint8).contiguous() if label_ok is not None else None
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+    with torch.cuda.device(dev):
+        check(lib.sparc_label_scores(n, ptr(rowptr), ptr(dst), ptr(w), ptr(labels), int(n_labels), ptr(ok), int(exclude_own),
+                                     ptr(best), ptr(best_lab), ptr(cur),
+                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "sparc_label_scores")
+    return best, best_lab, cur
+
+
+def _sweep(labels, src, dst, w, nw, cap, n_labels, parity, evict_to=None, pull_to=None, rowptr=None):
     """Every node selected by `parity` moves to the label its neighbours carry with the largest
     total weight if that beats its current label's weight and the target has room.
     With evict_to (the size every label must come down to) the sweep rebalances instead: only
@@ -36,6 +56,21 @@ def _sweep(labels, src, dst, w, nw, cap, n_labels, parity, evict_to=None, pull_t
     n = labels.numel()
     dev = labels.device
     size = torch.zeros(n_labels, dtype=torch.int64, device=dev).scatter_add_(0, labels, nw)
+    if rowptr is not None and labels.is_cuda:
+        # on the GPU the per-node label totals come from one kernel pass over the CSR adjacency (rowptr: the
+        # edge list is sorted by source); the torch formulation below is the same computation on any device
+        label_ok = None
+        if evict_to is not None:
+            label_ok = size < evict_to
+        if pull_to is not None:
+            label_ok = size < pull_to
+        best, best_lab, cur = _label_scores_kernel(labels.contiguous(), rowptr, dst.contiguous(), w.contiguous(), n_labels,
+                                                   label_ok, evict_to is not None or pull_to is not None)
+        if pull_to is not None:   # only nodes of labels that can spare one are drawn
+            spare = size[labels] > pull_to
+            best = torch.where(spare, best, torch.zeros_like(best))
+            best_lab = torch.where(spare, best_lab, torch.full_like(best_lab, n_labels))
+        return _sweep_moves(labels, nw, cap, n_labels, parity, evict_to, pull_to, size, best, best_lab, cur)
     key = src * n_labels + labels[dst]
     key, order = torch.sort(key)
     uniq, seg = torch.unique_consecutive(key, return_inverse=True)
@@ -55,6 +90,13 @@ def _sweep(labels, src, dst, w, nw, cap, n_labels, parity, evict_to=None, pull_t
     best = torch.zeros(n, dtype=torch.int64, device=dev).scatter_reduce_(0, u_of, score, "amax", include_self=True)
     cand = torch.where((score == best[u_of]) & (score > 0), lab_of, torch.full_like(lab_of, n_labels))
     best_lab = torch.full((n,), n_labels, dtype=torch.int64, device=dev).scatter_reduce_(0, u_of, cand, "amin", include_self=True)
+    return _sweep_moves(labels, nw, cap, n_labels, parity, evict_to, pull_to, size, best, best_lab, cur)
+
+
+def _sweep_moves(labels, nw, cap, n_labels, parity, evict_to, pull_to, size, best, best_lab, cur):
+    """Second half of a sweep: which of the proposed moves are carried out (gain, capacity, one target at a time)."""
+    n = labels.numel()
+    dev = labels.device
     gain = best - cur
     if pull_to is not None:
         want = (best_lab < n_labels) & parity
@@ -103,6 +145,14 @@ def _sweep(labels, src, dst, w, nw, cap, n_labels, parity, evict_to=None, pull_t
     out = labels.clone()
     out[idx] = tgt
     return out, int(idx.numel())
+
+
+def _rowptr(src, n):
+    """Row pointers of an edge list sorted by source (the kernel's CSR view of it); None on the CPU, where the
+    torch formulation of the sweep runs."""
+    if not src.is_cuda:
+        return None
+    return torch.searchsorted(src, torch.arange(n + 1, device=src.device, dtype=torch.int64))
 
 
 def _parity(n, t, dev):
@@ -180,7 +230,11 @@ def kway_partition(n: int, src: torch.Tensor, dst: torch.Tensor, k: int, imbalan
     if k == 1 or n == 0:
         return torch.zeros(n, dtype=torch.int64, device=dev)
     cap = _cap(n, k, imbalance)
-    graphs = [(src.to(torch.int64), dst.to(torch.int64), torch.ones(src.numel(), dtype=torch.int64, device=dev),
+    src, dst = src.to(torch.int64), dst.to(torch.int64)
+    if src.numel() > 1 and not bool((src[1:] >= src[:-1]).all()):   # the sweeps want the edges grouped by source
+        order = torch.sort(src, stable=True).indices
+        src, dst = src[order], dst[order]
+    graphs = [(src, dst, torch.ones(src.numel(), dtype=torch.int64, device=dev),
                torch.ones(n, dtype=torch.int64, device=dev))]
     maps = []
 
@@ -191,8 +245,9 @@ def kway_partition(n: int, src: torch.Tensor, dst: torch.Tensor, k: int, imbalan
         labels = torch.arange(cur_n, device=dev, dtype=torch.int64)
         ccap = max(2, cap // 8) if cur_n > 32 * k else max(2, cap // 2)
         idle = 0
+        rp = _rowptr(s_, cur_n)
         for t in range(coarsen_sweeps):
-            labels, moved = _sweep(labels, s_, d_, w_, nw_, ccap, cur_n, _parity(cur_n, t, dev))
+            labels, moved = _sweep(labels, s_, d_, w_, nw_, ccap, cur_n, _parity(cur_n, t, dev), rowptr=rp)
             idle = idle + 1 if moved == 0 else 0
             if idle == 2:   # both halves of the nodes had their turn
                 break
@@ -208,8 +263,9 @@ def kway_partition(n: int, src: torch.Tensor, dst: torch.Tensor, k: int, imbalan
     labels = torch.arange(cur_n, device=dev, dtype=torch.int64)
     if s_.numel() > 0:
         idle = 0
+        rp = _rowptr(s_, cur_n)
         for t in range(4 * coarsen_sweeps):
-            labels, moved = _sweep(labels, s_, d_, w_, nw_, cap, cur_n, _parity(cur_n, t, dev))
+            labels, moved = _sweep(labels, s_, d_, w_, nw_, cap, cur_n, _parity(cur_n, t, dev), rowptr=rp)
             idle = idle + 1 if moved == 0 else 0
             if idle == 2:
                 break
@@ -240,8 +296,9 @@ def kway_partition(n: int, src: torch.Tensor, dst: torch.Tensor, k: int, imbalan
             return part
         nn = int(part.numel())
         idle = 0
+        rp = _rowptr(s_, nn)
         for t in range(refine_sweeps):
-            part, moved = _sweep(part, s_, d_, w_, nw_, loose, k, _parity(nn, t0 + t, dev))
+            part, moved = _sweep(part, s_, d_, w_, nw_, loose, k, _parity(nn, t0 + t, dev), rowptr=rp)
             idle = idle + 1 if moved == 0 else 0
             if idle == 2:
                 break
@@ -254,10 +311,11 @@ def kway_partition(n: int, src: torch.Tensor, dst: torch.Tensor, k: int, imbalan
     # ---- bring every part back under the capacity (finest level: unit node weights) ...
     s_, d_, w_, nw_ = graphs[0]
     everyone = torch.ones(n, dtype=torch.bool, device=dev)
+    rp = _rowptr(s_, n)
     for _ in range(16):
         if int(torch.bincount(part, minlength=k).max()) <= cap or s_.numel() == 0:
             break
-        part, moved = _sweep(part, s_, d_, w_, nw_, cap, k, everyone, evict_to=cap)
+        part, moved = _sweep(part, s_, d_, w_, nw_, cap, k, everyone, evict_to=cap, rowptr=rp)
         if moved == 0:
             break
     # ---- ... and no part far below the mean: small parts draw in neighbours, then take what is left
@@ -265,7 +323,7 @@ def kway_partition(n: int, src: torch.Tensor, dst: torch.Tensor, k: int, imbalan
     for _ in range(8):
         if int(torch.bincount(part, minlength=k).min()) >= low or s_.numel() == 0:
             break
-        part, moved = _sweep(part, s_, d_, w_, nw_, low, k, everyone, pull_to=low)
+        part, moved = _sweep(part, s_, d_, w_, nw_, low, k, everyone, pull_to=low, rowptr=rp)
         if moved == 0:
             break
     return _fill_small_parts(part, k, low)
