@@ -42,9 +42,9 @@ __global__ __launch_bounds__(256) void gram_partial(int64_t m, int k, const floa
         cok[t] = t * 16 + li < k;
         col[t] = cok[t] ? t * 16 + li : 0;
     }
-    int64_t rb = w0;
-    for (; rb + 16 <= w1; rb += 16) {
-        float pf[4][NT], qf[4][NT];
+    // 16 rows per group; the loads of the next group are requested before the products of the current one
+    // (two register sets in turn)
+    auto load_group = [&](float (&pf)[4][NT], float (&qf)[4][NT], const int64_t rb) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int64_t r = rb + 4 * u + lk;
@@ -54,6 +54,8 @@ __global__ __launch_bounds__(256) void gram_partial(int64_t m, int k, const floa
                 qf[u][t] = Q[r * ldq + col[t]];
             }
         }
+    };
+    auto mul_group = [&](const float (&pf)[4][NT], const float (&qf)[4][NT]) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             double pa[NT], qb[NT];
@@ -66,6 +68,23 @@ __global__ __launch_bounds__(256) void gram_partial(int64_t m, int k, const floa
             for (int a = 0; a < NT; ++a)
 #pragma unroll
                 for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[a], qb[b], acc[a][b], 0, 0, 0);
+        }
+    };
+    int64_t rb = w0;
+    if (rb + 16 <= w1) {
+        float pf0[4][NT], qf0[4][NT], pf1[4][NT], qf1[4][NT];
+        load_group(pf0, qf0, rb);
+        for (;;) {
+            const bool more1 = rb + 32 <= w1;
+            if (more1) load_group(pf1, qf1, rb + 16);
+            mul_group(pf0, qf0);
+            rb += 16;
+            if (!more1) break;
+            const bool more0 = rb + 32 <= w1;
+            if (more0) load_group(pf0, qf0, rb + 16);
+            mul_group(pf1, qf1);
+            rb += 16;
+            if (!more0) break;
         }
     }
     for (; rb < w1; rb += 4) {  // last rows of the wave's range
@@ -107,17 +126,29 @@ __global__ __launch_bounds__(256) void gram_partial(int64_t m, int k, const floa
     for (int e = threadIdx.x; e < k * k; e += 256) out[e] = sm[(e / k) * KP + (e % k)];
 }
 
-__global__ void gram_reduce(int kk, int nparts, const double* __restrict__ slab, double* __restrict__ G) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= kk) return;
-    double t[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // eight independent chains, fixed order
-    int b = 0;
-    for (; b + 8 <= nparts; b += 8) {
+// G = sum of the block partials, in a fixed order: element e is summed by GRAM_SPLIT threads (thread h takes the
+// partials h, h + GRAM_SPLIT, ... in eight independent chains) and combined in thread order.
+constexpr int GRAM_SPLIT = 4;
+__global__ __launch_bounds__(256) void gram_reduce(int kk, int nparts, const double* __restrict__ slab, double* __restrict__ G) {
+    __shared__ double part[256];
+    const int local = threadIdx.x / GRAM_SPLIT, h = threadIdx.x % GRAM_SPLIT;
+    const int e = blockIdx.x * (256 / GRAM_SPLIT) + local;
+    double t[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (e < kk) {
+        int b = h;
+        for (; b + 7 * GRAM_SPLIT < nparts; b += 8 * GRAM_SPLIT) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] += slab[static_cast<int64_t>(b + u) * kk + e];
+            for (int u = 0; u < 8; ++u) t[u] += slab[static_cast<int64_t>(b + u * GRAM_SPLIT) * kk + e];
+        }
+        for (; b < nparts; b += GRAM_SPLIT) t[0] += slab[static_cast<int64_t>(b) * kk + e];
     }
-    for (; b < nparts; ++b) t[0] += slab[static_cast<int64_t>(b) * kk + e];
-    G[e] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    part[threadIdx.x] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    __syncthreads();
+    if (e < kk && h == 0) {
+        double sum = part[threadIdx.x];
+        for (int j = 1; j < GRAM_SPLIT; ++j) sum += part[threadIdx.x + j];
+        G[e] = sum;
+    }
 }
 
 // 1 / sqrt(x) in float64: the hardware estimate refined by two Newton steps
@@ -533,7 +564,7 @@ int gram_launch(int64_t m, int k, const float* A, int64_t lda, const float* B, i
         default: hipLaunchKernelGGL((gram_partial<4>), g, b, 0, stream, m, k, A, lda, B, ldb, rpb, slab); break;
     }
     SPARC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gram_reduce, dim3((k * k + 255) / 256), b, 0, stream, k * k, nparts, slab, G);
+    hipLaunchKernelGGL(gram_reduce, dim3((k * k * GRAM_SPLIT + 255) / 256), b, 0, stream, k * k, nparts, slab, G);
     SPARC_CHECK_LAUNCH();
     return SPARC_OK;
 }
