@@ -23,7 +23,7 @@ class Tiling(ctypes.Structure):
     """sparc_tiling_t of include/sparc_hip.h: a host struct describing a device tiling buffer."""
     _fields_ = [("buf", c_void_p), ("ndesc", c_int32), ("rows", c_int32), ("vec", c_int32), ("threads", c_int32),
                 ("kp", c_int32), ("dual", c_int32), ("s_addr", c_void_p), ("s_val", c_void_p), ("s_valT", c_void_p),
-                ("o_row", c_void_p), ("o_val", c_void_p), ("o_valT", c_void_p)]
+                ("o_row", c_void_p), ("o_val", c_void_p), ("o_valT", c_void_p), ("row_scale", c_void_p)]
 
 
 class Blocks(ctypes.Structure):

@@ -102,13 +102,17 @@ template <int VEC, bool DUAL, int EPI>
 __device__ __forceinline__ void row_epilogue(const SpmmArgs& a, const int64_t row, const int lane, const bool owner,
                                              const int half, const int cl, const bool right, const RowPre<VEC>& pre,
                                              const LapConst<VEC>& lc, float (&acc)[VEC], float* __restrict__ outp,
-                                             const int64_t colbase, double& wloss) {
+                                             const int64_t colbase, double& wloss, const float oscale = 1.f) {
     if (EPI == EPI_STORE) {
-        if (owner) store_vec<VEC>(outp, acc);
+        if (owner) {
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) acc[q] *= oscale;
+            store_vec<VEC>(outp, acc);
+        }
     } else if (EPI == EPI_ADD_X0) {
         if (owner) {
 #pragma unroll
-            for (int q = 0; q < VEC; ++q) acc[q] += pre.x0[q];
+            for (int q = 0; q < VEC; ++q) acc[q] = (acc[q] + pre.x0[q]) * oscale;
             store_vec<VEC>(outp, acc);
         }
     } else if (EPI == EPI_ADD_IDENT) {
@@ -295,7 +299,10 @@ struct Chunk4 {  // 64 in-window entries, four consecutive ones per lane of the 
 
 // The entry streams of a tiling are laid out in the order the lanes consume them and padded with
 // zero-weight entries, so a lane fetches its share with one 16-byte load per stream and no bounds logic.
-template <bool DUAL>
+// WT, the weights of an entry: 0 = one (val), 1 = two (val for the A half, valT for the A^T half), 2 = none
+// (pattern mode: the stored value is a product of a row factor and a column factor that the caller folds into
+// the epilogue and the operand, so the gather is a plain sum of operand rows).
+template <int WT>
 __device__ __forceinline__ Chunk4 load_entries4(const SpmmArgs& a, const unsigned pos, const bool live) {
     Chunk4 ck;
 #pragma unroll
@@ -306,10 +313,12 @@ __device__ __forceinline__ Chunk4 load_entries4(const SpmmArgs& a, const unsigne
     }
     if (live) {
         const int4 c = *reinterpret_cast<const int4*>(a.s_addr + pos);
-        const float4 v = *reinterpret_cast<const float4*>(a.s_val + pos);
         ck.addr[0] = c.x; ck.addr[1] = c.y; ck.addr[2] = c.z; ck.addr[3] = c.w;
-        ck.v[0] = v.x; ck.v[1] = v.y; ck.v[2] = v.z; ck.v[3] = v.w;
-        if (DUAL) {
+        if (WT != 2) {
+            const float4 v = *reinterpret_cast<const float4*>(a.s_val + pos);
+            ck.v[0] = v.x; ck.v[1] = v.y; ck.v[2] = v.z; ck.v[3] = v.w;
+        }
+        if (WT == 1) {
             const float4 vt = *reinterpret_cast<const float4*>(a.s_valT + pos);
             ck.vt[0] = vt.x; ck.vt[1] = vt.y; ck.vt[2] = vt.z; ck.vt[3] = vt.w;
         }
@@ -317,7 +326,7 @@ __device__ __forceinline__ Chunk4 load_entries4(const SpmmArgs& a, const unsigne
     return ck;
 }
 
-template <bool DUAL>
+template <int WT>
 __device__ __forceinline__ Chunk load_outside(const SpmmArgs& a, const unsigned pos, const bool live) {
     Chunk ck;
     ck.addr = 0;
@@ -325,8 +334,8 @@ __device__ __forceinline__ Chunk load_outside(const SpmmArgs& a, const unsigned 
     ck.vt = 0.f;
     if (live) {
         ck.addr = a.o_row[pos];
-        ck.v = a.o_val[pos];
-        if (DUAL) ck.vt = a.o_valT[pos];
+        if (WT != 2) ck.v = a.o_val[pos];
+        if (WT == 1) ck.vt = a.o_valT[pos];
     }
     return ck;
 }
@@ -340,10 +349,10 @@ __device__ __forceinline__ int bcast_add(const int x, const int base) {  // lane
     return __builtin_amdgcn_update_dpp(0, x, 0x150 + U, 0xf, 0xf, false) + base;
 }
 
-template <bool DUAL, int U>
+template <int WT, int U>
 __device__ __forceinline__ float bcast_weight(const float v, const float vt) {
     int w = __builtin_amdgcn_mov_dpp(__float_as_int(v), 0x150 + U, 0xf, 0xf, true);
-    if (DUAL) w = __builtin_amdgcn_update_dpp(w, __float_as_int(vt), 0x150 + U, 0xf, 0xc, false);
+    if (WT == 1) w = __builtin_amdgcn_update_dpp(w, __float_as_int(vt), 0x150 + U, 0xf, 0xc, false);
     return __int_as_float(w);
 }
 
@@ -353,10 +362,22 @@ __device__ __forceinline__ void vec_fma(float (&acc)[VEC], const float w, const 
     for (int q = 0; q < VEC; ++q) acc[q] = fmaf(w, x[q], acc[q]);
 }
 
+template <int VEC>
+__device__ __forceinline__ void vec_add(float (&acc)[VEC], const typename VecOf<VEC>::T x) {
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) acc[q] += x[q];
+}
+
+template <int VEC>
+__device__ __forceinline__ typename VecOf<VEC>::T lds_at(const int addr) {  // addr: LDS byte address
+    typedef typename VecOf<VEC>::T V;
+    return *(const __attribute__((address_space(3))) V*)(unsigned long)(unsigned)addr;
+}
+
 // The four in-window entries held by lane L of each DPP row: the four LDS reads are requested together and
 // the products alternate between two accumulators.  lane_base = this lane's column offset inside a
 // window row + the window's LDS base address.
-template <int VEC, bool DUAL, int L>
+template <int VEC, int WT, int L>
 __device__ __forceinline__ void lds_group(float (&acc0)[VEC], float (&acc1)[VEC], const Chunk4& ck, const int lane_base) {
     typedef typename VecOf<VEC>::T V;
     typedef __attribute__((address_space(3))) const V LdsV;
@@ -366,19 +387,26 @@ __device__ __forceinline__ void lds_group(float (&acc0)[VEC], float (&acc1)[VEC]
     const V x1 = *(LdsV*)(unsigned long)(unsigned)a1;
     const V x2 = *(LdsV*)(unsigned long)(unsigned)a2;
     const V x3 = *(LdsV*)(unsigned long)(unsigned)a3;
-    const float w0 = bcast_weight<DUAL, L>(ck.v[0], ck.vt[0]), w1 = bcast_weight<DUAL, L>(ck.v[1], ck.vt[1]);
-    const float w2 = bcast_weight<DUAL, L>(ck.v[2], ck.vt[2]), w3 = bcast_weight<DUAL, L>(ck.v[3], ck.vt[3]);
-    vec_fma<VEC>(acc0, w0, x0);
-    vec_fma<VEC>(acc1, w1, x1);
-    vec_fma<VEC>(acc0, w2, x2);
-    vec_fma<VEC>(acc1, w3, x3);
+    if (WT == 2) {
+        vec_add<VEC>(acc0, x0);
+        vec_add<VEC>(acc1, x1);
+        vec_add<VEC>(acc0, x2);
+        vec_add<VEC>(acc1, x3);
+    } else {
+        const float w0 = bcast_weight<WT, L>(ck.v[0], ck.vt[0]), w1 = bcast_weight<WT, L>(ck.v[1], ck.vt[1]);
+        const float w2 = bcast_weight<WT, L>(ck.v[2], ck.vt[2]), w3 = bcast_weight<WT, L>(ck.v[3], ck.vt[3]);
+        vec_fma<VEC>(acc0, w0, x0);
+        vec_fma<VEC>(acc1, w1, x1);
+        vec_fma<VEC>(acc0, w2, x2);
+        vec_fma<VEC>(acc1, w3, x3);
+    }
 }
 
 // The first `groups` (1..16, wave-uniform) lanes' entries of an in-window chunk (padding entries carry a zero weight)
-template <int VEC, bool DUAL>
+template <int VEC, int WT>
 __device__ __forceinline__ void lds_chunk(float (&acc0)[VEC], float (&acc1)[VEC], const Chunk4& ck, const int groups,
                                           const int lane_base) {
-#define SPARC_G(L) if (groups > L) lds_group<VEC, DUAL, L>(acc0, acc1, ck, lane_base);
+#define SPARC_G(L) if (groups > L) lds_group<VEC, WT, L>(acc0, acc1, ck, lane_base);
     SPARC_G(0) SPARC_G(1) SPARC_G(2) SPARC_G(3) SPARC_G(4) SPARC_G(5) SPARC_G(6) SPARC_G(7)
     SPARC_G(8) SPARC_G(9) SPARC_G(10) SPARC_G(11) SPARC_G(12) SPARC_G(13) SPARC_G(14) SPARC_G(15)
 #undef SPARC_G
@@ -406,16 +434,17 @@ __device__ __forceinline__ void outside_issue(OutsideG<VEC>& o, const Chunk& ck,
     }
 }
 
-template <int VEC, bool DUAL, int U, int Q = 0>
+template <int VEC, int WT, int U, int Q = 0>
 __device__ __forceinline__ void outside_use(float (&acc0)[VEC], float (&acc1)[VEC], const Chunk& ck, const OutsideG<VEC>& o) {
     if constexpr (Q < OutsideG<VEC>::N) {
-        vec_fma<VEC>((Q & 1) ? acc1 : acc0, bcast_weight<DUAL, (U + Q) & 15>(ck.v, ck.vt), o.x[Q]);
-        outside_use<VEC, DUAL, U, Q + 1>(acc0, acc1, ck, o);
+        if (WT == 2) vec_add<VEC>((Q & 1) ? acc1 : acc0, o.x[Q]);
+        else vec_fma<VEC>((Q & 1) ? acc1 : acc0, bcast_weight<WT, (U + Q) & 15>(ck.v, ck.vt), o.x[Q]);
+        outside_use<VEC, WT, U, Q + 1>(acc0, acc1, ck, o);
     }
 }
 
 // steps [first, steps) of an outside chunk (first: a multiple of the group size), one group of loads at a time
-template <int VEC, bool DUAL>
+template <int VEC, int WT>
 __device__ __forceinline__ void outside_chunk(float (&acc0)[VEC], float (&acc1)[VEC], const Chunk& ck, const int first,
                                               const int steps, const float* __restrict__ lane_ptr) {
     constexpr int N = OutsideG<VEC>::N;
@@ -423,16 +452,26 @@ __device__ __forceinline__ void outside_chunk(float (&acc0)[VEC], float (&acc1)[
     if (U % N == 0 && first <= U && steps > U) {                 \
         OutsideG<VEC> o;                                         \
         outside_issue<VEC, U>(o, ck, lane_ptr);                  \
-        outside_use<VEC, DUAL, U>(acc0, acc1, ck, o);            \
+        outside_use<VEC, WT, U>(acc0, acc1, ck, o);              \
     }
     SPARC_O(0) SPARC_O(4) SPARC_O(8) SPARC_O(12)
 #undef SPARC_O
 }
 
-template <int VEC, bool DUAL, int EPI, bool SYM>
+// WM, how the stored values enter: 0 = val (and valT for the A^T half of a training pass), 1 = training pass on a
+// numerically symmetric matrix (valT == val: one weight per entry for both halves), 2 = pattern mode: every
+// off-diagonal value is A[i][j] = r_i (the supports the reference builds from a 0/1 adjacency: A + I,
+// D^-1 (A + I), with or without the diagonal enhancement), so that
+//     (A x)_i = r_i sum_j x_j + delta_i x_i,      (A^T x)_i = sum_j (r_j x_j) + delta_i x_i,      delta_i = A[i][i] - r_i
+// (sums over the stored pattern of row i).  The gathered operand then carries the A^T half pre-multiplied by r
+// (the epilogue writes it that way), the gather is a plain sum of operand rows (no weight streams, no
+// weight broadcasts), and the row factors come back in the epilogue (a.rowpat: {r, delta, delta / r, 0} per row).
+// Padding entries of the in-window stream point at one extra, zeroed window row; outside entries keep a 0/1 weight.
+template <int VEC, bool DUAL, int EPI, int WM>
 __global__ __launch_bounds__(WIN_MAX_THREADS) void spmm_win(const SpmmArgs a) {
-    // SYM (training pass on a numerically symmetric matrix): valT == val, one weight per entry for both halves
-    constexpr bool TWO = DUAL && !SYM;
+    constexpr bool PAT = WM == 2;
+    constexpr int WT = PAT ? 2 : (DUAL && WM == 0) ? 1 : 0;   // weights of the in-window entries
+    constexpr int WTO = PAT ? 0 : WT;                          // ... and of the outside entries
     // the widest variants keep one slot's operands in registers at a time (no request one slot ahead)
     constexpr bool AHEAD = !(VEC == 4 && (EPI == EPI_LAP_SINGLE || EPI == EPI_LAP_DUAL));
     extern __shared__ float4 tile[];  // [window rows][16 lanes][VEC floats]
@@ -478,6 +517,7 @@ __global__ __launch_bounds__(WIN_MAX_THREADS) void spmm_win(const SpmmArgs a) {
                                                  (__attribute__((address_space(3))) void*)(info + base), 16, 0, 0);
         }
     }
+    if (PAT && threadIdx.x < RW) reinterpret_cast<float*>(tile)[wn * RW + threadIdx.x] = 0.f;  // the row padding entries point at
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's copies into LDS have landed
     __syncthreads();                     // ... and so have everybody else's
     if (a.stamps) t_bar = __builtin_readcyclecounter();
@@ -495,6 +535,7 @@ __global__ __launch_bounds__(WIN_MAX_THREADS) void spmm_win(const SpmmArgs a) {
         Chunk4 c0;  // the first in-window chunk: all of a short row
         Chunk o0;   // the first outside chunk
         float x0[VEC];  // the row's own operand of the epilogue
+        float4 rp;      // pattern mode: {r, delta, delta / r, 0} of the row
     };
     const bool has_out = d[6] != 0;  // any of this workgroup's rows has entries outside the window
     const unsigned lane4 = (lr * 4 + g) * 4, lane1 = lr * 4 + g;  // this lane's place inside a chunk of either stream
@@ -504,12 +545,14 @@ __global__ __launch_bounds__(WIN_MAX_THREADS) void spmm_win(const SpmmArgs a) {
         int4 ri = make_int4(-1, 0, 0, 0);
         if (slot < nslots) ri = info[slot * 4 + g];
         s.ri = ri;
-        s.c0 = load_entries4<TWO>(a, static_cast<unsigned>(ri.y) + lane4, lr < (ri.w & 0xffff));
+        s.c0 = load_entries4<WT>(a, static_cast<unsigned>(ri.y) + lane4, lr < (ri.w & 0xffff));
         s.o0.addr = 0; s.o0.v = 0.f; s.o0.vt = 0.f;
-        if (has_out) s.o0 = load_outside<TWO>(a, static_cast<unsigned>(ri.z) + lane1, lr < (ri.w >> 16));
+        if (has_out) s.o0 = load_outside<WTO>(a, static_cast<unsigned>(ri.z) + lane1, lr < (ri.w >> 16));
 #pragma unroll
         for (int q = 0; q < VEC; ++q) s.x0[q] = 0.f;
         if (EPI != EPI_STORE) load_vec<VEC>(s.x0, X0s + static_cast<int64_t>(ri.x >= 0 ? ri.x : 0) * RW);
+        s.rp = make_float4(1.f, 0.f, 0.f, 0.f);
+        if (PAT) s.rp = *reinterpret_cast<const float4*>(a.rowpat + static_cast<int64_t>(ri.x >= 0 ? ri.x : 0) * 4);
     };
 
     const int lane_base = lr * (VEC * 4) + (int)(unsigned long)(__attribute__((address_space(3))) const char*)tile;
@@ -537,21 +580,21 @@ __global__ __launch_bounds__(WIN_MAX_THREADS) void spmm_win(const SpmmArgs a) {
             osteps = __builtin_amdgcn_readfirstlane(ri.w >> 16);
             if (osteps > 0) outside_issue<VEC, 0>(og, cur.o0, Xs);
         }
-        if (groups > 0) lds_chunk<VEC, TWO>(acc, acc1, cur.c0, min(groups, 16), lane_base);
+        if (groups > 0) lds_chunk<VEC, WT>(acc, acc1, cur.c0, min(groups, 16), lane_base);
         if (groups > 16) {  // rows of more than 256 in-window entries: the next chunk is requested before this one is used
-            Chunk4 ck = load_entries4<TWO>(a, static_cast<unsigned>(ri.y) + 256 + lane4, lr + 16 < groups);
+            Chunk4 ck = load_entries4<WT>(a, static_cast<unsigned>(ri.y) + 256 + lane4, lr + 16 < groups);
             for (int c = 1; c * 16 < groups; ++c) {
-                const Chunk4 cn = load_entries4<TWO>(a, static_cast<unsigned>(ri.y) + (c + 1) * 256 + lane4, lr + (c + 1) * 16 < groups);
-                lds_chunk<VEC, TWO>(acc, acc1, ck, min(groups - c * 16, 16), lane_base);
+                const Chunk4 cn = load_entries4<WT>(a, static_cast<unsigned>(ri.y) + (c + 1) * 256 + lane4, lr + (c + 1) * 16 < groups);
+                lds_chunk<VEC, WT>(acc, acc1, ck, min(groups - c * 16, 16), lane_base);
                 ck = cn;
             }
         }
         if (osteps > 0) {
-            outside_use<VEC, TWO, 0>(acc, acc1, cur.o0, og);
-            outside_chunk<VEC, TWO>(acc, acc1, cur.o0, OutsideG<VEC>::N, min(osteps, 16), Xs);
+            outside_use<VEC, WTO, 0>(acc, acc1, cur.o0, og);
+            outside_chunk<VEC, WTO>(acc, acc1, cur.o0, OutsideG<VEC>::N, min(osteps, 16), Xs);
             for (int c = 1; c * 16 < osteps; ++c) {
-                const Chunk ck = load_outside<TWO>(a, static_cast<unsigned>(ri.z) + c * 64 + lane1, lr + c * 16 < osteps);
-                outside_chunk<VEC, TWO>(acc, acc1, ck, 0, min(osteps - c * 16, 16), Xs);
+                const Chunk ck = load_outside<WTO>(a, static_cast<unsigned>(ri.z) + c * 64 + lane1, lr + c * 16 < osteps);
+                outside_chunk<VEC, WTO>(acc, acc1, ck, 0, min(osteps - c * 16, 16), Xs);
             }
         }
 #pragma unroll
@@ -564,8 +607,15 @@ __global__ __launch_bounds__(WIN_MAX_THREADS) void spmm_win(const SpmmArgs a) {
             }
         }
         const bool owner = valid && (!lng || g == 0);
+        float oscale = 1.f;
+        if (PAT) {  // back to the matrix's own scale: the row factor, and the diagonal's share beyond it
+            const V own = lds_at<VEC>(lane_base + (valid ? static_cast<int>(row) - w0 : 0) * ROWB);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) acc[q] = right ? fmaf(cur.rp.z, own[q], acc[q]) : fmaf(cur.rp.x, acc[q], cur.rp.y * own[q]);
+            if (right) oscale = cur.rp.x;   // the next pass gathers the A^T half pre-multiplied by r
+        }
         row_epilogue<VEC, DUAL, EPI>(a, row, lane, owner, 8, cl, right, pre, lc, acc, outs ? outs + row * RW : nullptr, 0,
-                                     wloss);
+                                     wloss, oscale);
     };
     if (AHEAD) {  // two slots in turn, so that no register that a load is still writing has to be copied
         Slot sa, sb;
@@ -610,7 +660,8 @@ __global__ __launch_bounds__(WIN_MAX_THREADS) void spmm_win(const SpmmArgs a) {
 template <int KP, bool DUAL>
 __global__ __launch_bounds__(256) void lap_scale(int64_t m, int k, int64_t ldy, const float* __restrict__ Y,
                                                  const float* __restrict__ rowc, float* __restrict__ X, int hw, int rw,
-                                                 int64_t plane, float* __restrict__ colpart, int64_t rows_per_block) {
+                                                 int64_t plane, float* __restrict__ colpart, int64_t rows_per_block,
+                                                 float* __restrict__ G, const float* __restrict__ rowpat) {
     constexpr int RG = 256 / KP;
     constexpr int NS = DUAL ? 6 : 3;
     const int col = threadIdx.x % KP, rg = threadIdx.x / KP;
@@ -625,12 +676,14 @@ __global__ __launch_bounds__(256) void lap_scale(int64_t m, int k, int64_t ldy, 
             const float4 rc1 = *reinterpret_cast<const float4*>(rowc + r * SPARC_ROWC + 4);
             const float y = (col < k) ? Y[r * ldy + col] * rc0.w : 0.f;
             X[xoff + r * rw] = y;
+            if (G) G[xoff + r * rw] = y;   // pattern mode: the first gathered operand, A^T half times the row factor
             s[0] += y;
             s[1] += rc1.z * y;
             s[2] += rc1.w * y;
             if (DUAL) {
                 const float x2 = y * fabsf(rc0.x);
                 X[xoff + r * rw + hw] = x2;
+                if (G) G[xoff + r * rw + hw] = x2 * rowpat[r * 4];
                 s[3] += x2;
                 s[4] += rc1.x * x2;
                 s[5] += rc1.y * x2;
@@ -745,7 +798,7 @@ int launch_rows(const SpmmArgs& a, hipStream_t stream) {
 long long* g_stamps = nullptr;  // developer timeline buffer (SPARC_DBG & 64), set by sparc_debug_stamps
 
 // Per device and per instantiation: allow the large dynamic LDS allocation.
-template <int VEC, bool DUAL, int EPI, bool SYM>
+template <int VEC, bool DUAL, int EPI, int WM>
 int configure_win() {
     static std::mutex mu;
     static bool done[64] = {};
@@ -753,20 +806,20 @@ int configure_win() {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SPARC_ERR_LAUNCH;
     std::lock_guard<std::mutex> lock(mu);
     if (!done[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_win<VEC, DUAL, EPI, SYM>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, SPARC_TILE_LDS_BYTES) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_win<VEC, DUAL, EPI, WM>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, SPARC_TILE_LDS_BYTES + 256) != hipSuccess)
             return SPARC_ERR_LAUNCH;
         done[dev] = true;
     }
     return SPARC_OK;
 }
 
-template <int VEC, bool DUAL, int EPI, bool SYM = false>
+template <int VEC, bool DUAL, int EPI, int WM = 0>
 int launch_win(const SpmmArgs& a, hipStream_t stream) {
     if (a.ndesc <= 0) return SPARC_OK;
-    const size_t lds = static_cast<size_t>(a.tile_rows) * 64 * VEC;
-    if (lds > SPARC_TILE_LDS_BYTES || a.threads < 64 || a.threads > WIN_MAX_THREADS || a.threads % 64) return SPARC_ERR_ARG;
-    const int rc = configure_win<VEC, DUAL, EPI, SYM>();
+    const size_t lds = static_cast<size_t>(a.tile_rows + (WM == 2 ? 1 : 0)) * 64 * VEC;   // pattern mode: one more, zeroed row
+    if (lds > SPARC_TILE_LDS_BYTES + 256 || a.threads < 64 || a.threads > WIN_MAX_THREADS || a.threads % 64) return SPARC_ERR_ARG;
+    const int rc = configure_win<VEC, DUAL, EPI, WM>();
     if (rc) return rc;
     SpmmArgs b = a;
     static const int dbg = [] {  // developer switch for kernel ablation timings, read once
@@ -775,14 +828,17 @@ int launch_win(const SpmmArgs& a, hipStream_t stream) {
     }();
     b.dbg = dbg;
     b.stamps = (dbg & 64) && EPI == EPI_ADD_X0 ? g_stamps : nullptr;
-    hipLaunchKernelGGL((spmm_win<VEC, DUAL, EPI, SYM>), dim3(static_cast<unsigned>(a.ndesc)), dim3(a.threads), lds, stream, b);
+    hipLaunchKernelGGL((spmm_win<VEC, DUAL, EPI, WM>), dim3(static_cast<unsigned>(a.ndesc)), dim3(a.threads), lds, stream, b);
     SPARC_CHECK_LAUNCH();
     return SPARC_OK;
 }
 
 template <int EPI>
 int launch_single(int width, const SpmmArgs& a, hipStream_t s) {
-    if (a.desc) return a.vec == 2 ? launch_win<2, false, EPI>(a, s) : launch_win<4, false, EPI>(a, s);
+    if (a.desc) {
+        if (a.rowpat) return a.vec == 2 ? launch_win<2, false, EPI, 2>(a, s) : launch_win<4, false, EPI, 2>(a, s);
+        return a.vec == 2 ? launch_win<2, false, EPI>(a, s) : launch_win<4, false, EPI>(a, s);
+    }
     switch (width) {
         case 16: return launch_rows<4, false, EPI>(a, s);
         case 32: return launch_rows<8, false, EPI>(a, s);
@@ -795,8 +851,9 @@ int launch_single(int width, const SpmmArgs& a, hipStream_t s) {
 template <int EPI>
 int launch_dual(int kp, const SpmmArgs& a, hipStream_t s) {
     if (a.desc) {
+        if (a.rowpat) return a.vec == 2 ? launch_win<2, true, EPI, 2>(a, s) : launch_win<4, true, EPI, 2>(a, s);
         if (a.s_valT == a.s_val && a.o_valT == a.o_val)   // numerically symmetric matrix: one weight per entry
-            return a.vec == 2 ? launch_win<2, true, EPI, true>(a, s) : launch_win<4, true, EPI, true>(a, s);
+            return a.vec == 2 ? launch_win<2, true, EPI, 1>(a, s) : launch_win<4, true, EPI, 1>(a, s);
         return a.vec == 2 ? launch_win<2, true, EPI>(a, s) : launch_win<4, true, EPI>(a, s);
     }
     switch (kp) {
@@ -812,6 +869,7 @@ int launch_dual(int kp, const SpmmArgs& a, hipStream_t s) {
 int set_tiling(SpmmArgs& a, const sparc_tiling_t* t, int64_t m, bool dual, int kp) {
     a.desc = nullptr;
     a.rowinfo = nullptr;
+    a.rowpat = nullptr;
     a.ndesc = 0;
     if (!t) return SPARC_OK;
     const int hw = dual ? 8 * t->vec : 16 * t->vec;   // columns of a half (dual) or of the row (single) per slab
@@ -819,7 +877,10 @@ int set_tiling(SpmmArgs& a, const sparc_tiling_t* t, int64_t m, bool dual, int k
         static_cast<size_t>(t->rows) * 64 * t->vec > SPARC_TILE_LDS_BYTES || (t->dual != 0) != dual || t->kp != kp ||
         kp % hw != 0 || t->threads < 64 || t->threads > WIN_MAX_THREADS || t->threads % 64)
         return SPARC_ERR_ARG;
-    if (!t->s_addr || !t->s_val || (dual && !t->s_valT) || !t->o_row || !t->o_val || (dual && !t->o_valT)) return SPARC_ERR_ARG;
+    const bool pattern = t->s_val == nullptr;   // no weight streams: every off-diagonal value is its row's factor
+    if (!t->s_addr || !t->o_row || !t->o_val) return SPARC_ERR_ARG;
+    if (pattern ? !t->row_scale : ((dual && !t->s_valT) || (dual && !t->o_valT))) return SPARC_ERR_ARG;
+    a.rowpat = pattern ? t->row_scale : nullptr;
     a.desc = t->buf;
     a.rowinfo = t->buf + static_cast<int64_t>(t->ndesc) * 8;  // the slot records follow the descriptors
     a.s_addr = t->s_addr; a.s_val = t->s_val; a.s_valT = t->s_valT;
@@ -987,14 +1048,16 @@ int lap_fwd_impl(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* c
     const int rw = tiled ? 16 * tiling->vec : W;
     const int64_t plane = tiled ? a.plane : 0;
 
+    // pattern mode: the first pass gathers G0 = [X_A | r X_T], kept in P2 until the second pass overwrites it
+    float* G0 = a.rowpat ? P2 : nullptr;
     const dim3 gs(static_cast<unsigned>(p.nscale)), bs(256);
 #define SPARC_SCALE(KP)                                                                                              \
     if (dual)                                                                                                        \
         hipLaunchKernelGGL((lap_scale<KP, true>), gs, bs, 0, stream, m, k, ldy, Y, rowc, X, hw, rw, plane, colpart,   \
-                           p.rows_per_block);                                                                        \
+                           p.rows_per_block, G0, a.rowpat);                                                                        \
     else                                                                                                             \
         hipLaunchKernelGGL((lap_scale<KP, false>), gs, bs, 0, stream, m, k, ldy, Y, rowc, X, hw, rw, plane, colpart,  \
-                           p.rows_per_block);
+                           p.rows_per_block, G0, a.rowpat);
     if (kp == 16) { SPARC_SCALE(16) } else if (kp == 32) { SPARC_SCALE(32) } else if (kp == 48) { SPARC_SCALE(48) } else { SPARC_SCALE(64) }
 #undef SPARC_SCALE
     SPARC_CHECK_LAUNCH();
@@ -1008,7 +1071,7 @@ int lap_fwd_impl(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* c
     // (plus the own-row operand), then the row kernel over the remaining entries, which adds its gathers to it.
     {
         Timed both(EPI_ADD_X0, stream, 2);   // the two inner passes, back to back
-        a.Xg = X; a.out = P1;
+        a.Xg = G0 ? G0 : X; a.out = P1;
         if (blocks) {
             bl.Xg = X; bl.X0 = X; bl.out = P1;
             if ((rcode = sparc_blocks_launch(bl, true, fuse, stream))) return rcode;

@@ -257,6 +257,7 @@ class ClusterBatch:
         self._windows = plan_windows(m, cluster_sizes)
         self._tiles = {}
         self._blocks = None
+        self._row_factors = None
         self._measured = {}
         self._window_ranges = None
         self._prepare(eps)
@@ -315,9 +316,10 @@ class ClusterBatch:
         vec, kp, n_slabs = geo
         threads = self.tile_threads or (512 if vec == 2 else 1024)
         target = self.tile_target_wgs or (2 * N_CU if vec == 2 else N_CU)
-        key = (vec, kp, bool(training), threads, target)
+        pattern = self.use_pattern and self.row_factors() is not None
+        key = (vec, kp, bool(training), threads, target, pattern)
         if key not in self._tiles:
-            self._tiles[key] = self._plan(vec, kp, n_slabs, bool(training), threads, target)
+            self._tiles[key] = self._plan(vec, kp, n_slabs, bool(training), threads, target, pattern=pattern)
         return self._tiles[key]
 
     # ---- dense diagonal blocks ------------------------------------------------------------------
@@ -396,7 +398,45 @@ class ClusterBatch:
         return {"struct": b, "keep": (desc_d, blk, blkT), "max_p": int(P.max()), "fill": fill, "ndesc": int(desc_d.shape[0]),
                 "r_rowptr": r_rowptr, "r_col": r_col, "r_val": r_val, "r_valT": r_valT, "r_nnz": int(rest.sum())}
 
-    def _plan(self, vec, kp, n_slabs, dual, threads, target, mirrored=False):
+    use_pattern = True   # class-wide switch: weight-free gathers for supports whose off-diagonal values are row factors
+
+    def row_factors(self):
+        """float32 [m, 4] = {r, delta, delta / r, 0} when every off-diagonal value of the support is its row's
+        factor, A[i][j] = r_i (and the mirrored value therefore r_j): the supports src/utils.py builds from a 0/1
+        adjacency (A + I, D^-1 (A + I), with or without the diagonal enhancement); delta_i = A[i][i] - r_i (0 without
+        a stored diagonal).  None otherwise.  Checked exactly, once per batch."""
+        if self._row_factors is None:
+            self._row_factors = self._find_row_factors()
+        return self._row_factors if self._row_factors is not False else None
+
+    def _find_row_factors(self):
+        if self.nnz == 0:
+            return False
+        dev, m = self.device, self.m
+        counts = self.rowptr[1:] - self.rowptr[:-1]
+        row = torch.repeat_interleave(torch.arange(m, device=dev), counts)
+        col = self.colidx.to(torch.int64)
+        off = row != col
+        inf = torch.full((m,), float("inf"), dtype=torch.float32, device=dev)
+        lo = inf.clone().scatter_reduce_(0, row[off], self.val[off], "amin", include_self=True)
+        hi = (-inf).scatter_reduce_(0, row[off], self.val[off], "amax", include_self=True)
+        has = torch.isfinite(lo)
+        diag = torch.zeros(m, dtype=torch.float32, device=dev)
+        has_diag = torch.zeros(m, dtype=torch.bool, device=dev)
+        diag[row[~off]] = self.val[~off]
+        has_diag[row[~off]] = True
+        if bool((lo[has] != hi[has]).any()):
+            return False
+        r = torch.where(has, lo, torch.where(has_diag & (diag != 0), diag, torch.ones_like(lo)))   # rows without neighbours
+        if bool((r == 0).any()) or not bool(torch.isfinite(r).all()):
+            return False
+        valT = self.valT if self.valT is not None else self.val
+        if bool((valT[off] != r[col[off]]).any()) or bool((valT[~off] != self.val[~off]).any()):
+            return False
+        delta = torch.where(has_diag, diag - r, torch.zeros_like(r))
+        return torch.stack([r, delta, delta / r, torch.zeros_like(r)], dim=1).contiguous()
+
+    def _plan(self, vec, kp, n_slabs, dual, threads, target, mirrored=False, pattern=False):
         """Tiling for one kernel geometry: work descriptors and slot records (planned on the host) and the
         entry streams in consumption order (scattered on the device).  mirrored: bake the mirrored values
         into the single-width stream (for A^T X)."""
@@ -442,13 +482,33 @@ class ClusterBatch:
         v_main, v_mirr = (valT, self.val) if mirrored else (self.val, valT)
         n_s, n_o = pl["stream_len"] + 16, pl["ostream_len"] + 16
         s_addr = torch.zeros(n_s, dtype=torch.int32, device=dev)
-        s_val = torch.zeros(n_s, dtype=torch.float32, device=dev)
         o_row = torch.zeros(n_o, dtype=torch.int32, device=dev)
         o_val = torch.zeros(n_o, dtype=torch.float32, device=dev)
         pi, po = pos_in[inside], pos_out[~inside]
+        o_row[po] = self.colidx[~inside]
+        if pattern:
+            # no weight streams: padding entries point at the zeroed row behind the slot's window, outside entries
+            # carry a 0/1 weight
+            we = np.empty(m, np.int64)
+            for a, b in self._windows:
+                we[a:b] = b - a
+            first = np.maximum(pl["slot_rows"][:, 0], 0)
+            pad = up(we[first] * (64 * vec))
+            if len(pl["slot_L"]):
+                s_addr[:pl["stream_len"]] = torch.repeat_interleave(pad, up(pl["slot_L"] * 16)).to(torch.int32)
+            s_addr[pi] = ((col[inside] - r_w0[row[inside]]) * (64 * vec)).to(torch.int32)
+            o_val[po] = 1.0
+            rf = self.row_factors()
+            t = _lib.Tiling(buf.data_ptr(), int(pl["desc"].shape[0]), int(rows), vec, threads, kp, int(dual),
+                            s_addr.data_ptr(), None, None, o_row.data_ptr(), o_val.data_ptr(), None, rf.data_ptr())
+            t.keep = (buf, s_addr, o_row, o_val, rf)
+            t.plan = pl
+            t.desc = pl["desc"]
+            t.pattern = True
+            return t
+        s_val = torch.zeros(n_s, dtype=torch.float32, device=dev)
         s_addr[pi] = ((col[inside] - r_w0[row[inside]]) * (64 * vec)).to(torch.int32)
         s_val[pi] = v_main[inside]
-        o_row[po] = self.colidx[~inside]
         o_val[po] = v_main[~inside]
         s_valT = o_valT = None
         if dual:
@@ -461,8 +521,9 @@ class ClusterBatch:
                 o_valT[po] = v_mirr[~inside]
         t = _lib.Tiling(buf.data_ptr(), int(pl["desc"].shape[0]), int(rows), vec, threads, kp, int(dual),
                         s_addr.data_ptr(), s_val.data_ptr(), s_valT.data_ptr() if s_valT is not None else None,
-                        o_row.data_ptr(), o_val.data_ptr(), o_valT.data_ptr() if o_valT is not None else None)
+                        o_row.data_ptr(), o_val.data_ptr(), o_valT.data_ptr() if o_valT is not None else None, None)
         t.keep = (buf, s_addr, s_val, s_valT, o_row, o_val, o_valT)   # the struct points into these tensors
+        t.pattern = False
         t.plan = pl
         t.desc = pl["desc"]
         return t

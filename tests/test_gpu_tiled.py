@@ -275,3 +275,64 @@ def test_kernel_choice_by_share_and_by_measurement(dev, monkeypatch):
     l1, g1 = br2.lap(Y, True)                    # whichever kernel was kept
     l0, g0 = br.lap(Y, True)                     # the row kernel
     assert rel(l1.item(), l0.item()) < 1e-5 and rel(g1.cpu().numpy(), g0.cpu().numpy()) < 1e-5
+
+
+# ---- pattern mode: supports built from a 0/1 adjacency, whose off-diagonal values are row factors -------------
+@pytest.fixture(scope="module")
+def binary_fixture():
+    rng = np.random.default_rng(77)
+    D = windowed_pattern(rng, SIZES, big_hubs=3)
+    D = sp.csr_matrix((D > 0) * 1.0)                    # 0/1 adjacency + identity
+    nodiag = sp.csr_matrix(D - sp.diags(D.diagonal()))
+    out = {}
+    for flavour, M in (("raw_bin", D), ("rownorm_bin", O.row_normalize(D)), ("enh_bin", O.row_normalize_diag_enhance(D, 0.01)),
+                       ("nodiag_bin", nodiag)):
+        s = O.as_support_tuple(sp.csr_matrix(M))
+        A, At = O.csr_from_support(s)
+        out[flavour] = (s, A, At, O.affinity_prep_operator(A))
+    return out
+
+
+@pytest.mark.parametrize("flavour", ["raw_bin", "rownorm_bin", "enh_bin", "nodiag_bin"])
+@pytest.mark.parametrize("k", [7, 32, 47, 64])
+def test_pattern_mode_lap_matches_oracle(dev, binary_fixture, flavour, k, monkeypatch):
+    """Weight-free gathers (row factors in the epilogue, A^T half of the operand pre-multiplied): every row class of
+    the windowed kernel again, on the three support flavours of the reference built from a 0/1 adjacency and on
+    a support without stored diagonal; against the oracle, and against the weighted streams on the same batch."""
+    from sparc_amd.graph import ClusterBatch
+    s, A, _, prep = binary_fixture[flavour]
+    m = A.shape[0]
+    rng = np.random.default_rng(k)
+    Y = rng.standard_normal((m, k)).astype(np.float32)
+    loss_o, g_o, _, _ = O.lap_forward_operator(A, prep, Y.astype(np.float64))
+    b = ClusterBatch.from_support(s, dev, cluster_sizes=SIZES)
+    rf = b.row_factors()
+    assert rf is not None and rf.shape == (m, 4)
+    if flavour == "enh_bin":
+        assert float(rf[:, 1].abs().max()) > 0          # the enhanced diagonal is not the row factor
+    cen = tiling_census(b, k, True)
+    assert b.tiling(k, True).pattern
+    for key in ("len_17_32", "len_33_64", "len_65_128", "len_gt128", "len_gt256", "out1", "out_5_16", "out_gt16", "long_with_out"):
+        assert cen[key] > 0, (key, cen)
+    Yd = torch.tensor(Y, device=dev)
+    loss, grad = b.lap(Yd, True)
+    assert rel(loss.item(), loss_o) < TOL, cen
+    assert rel(grad.cpu().numpy(), g_o) < TOL, cen
+    gn = np.abs(g_o).max(axis=1)
+    err_rows = np.abs(grad.cpu().numpy() - g_o).max(axis=1) / np.maximum(gn, 1e-3 * gn.max())
+    assert err_rows.max() < 5e-4, int(err_rows.argmax())
+    if k > 16:
+        assert b.tiling(k, False).pattern
+        lv, none = b.lap(Yd, False)
+        assert none is None and rel(lv.item(), loss_o) < TOL
+    monkeypatch.setattr(ClusterBatch, "use_pattern", False)     # the same batch through the weight streams
+    assert not b.tiling(k, True).pattern
+    loss_w, grad_w = b.lap(Yd, True)
+    assert rel(loss_w.item(), loss.item()) < 1e-5 and rel(grad_w.cpu().numpy(), grad.cpu().numpy()) < 2e-5
+
+
+def test_weighted_supports_have_no_row_factors(dev, big_fixture):
+    from sparc_amd.graph import ClusterBatch
+    for flavour in ("enh", "raw"):                      # weights 1 and 2 inside a row
+        b = ClusterBatch.from_support(big_fixture[flavour][0], dev, cluster_sizes=SIZES)
+        assert b.row_factors() is None and not b.tiling(47, True).pattern

@@ -16,6 +16,8 @@ from sparc_amd.graph import ClusterBatch
 dev = torch.device("cuda:0")
 workload = os.environ.get("WORKLOAD", "amazon2m")
 bsize = int(os.environ.get("BSIZE", "0")) or None
+if os.environ.get("LAM"):      # another support flavour of the same graph (-1: raw symmetric values)
+    synth.SHAPES[workload] = dict(synth.SHAPES[workload], diag_lambda=float(os.environ["LAM"]))
 b, k = synth.shape_batch(workload, dev, bsize=bsize)
 k = int(os.environ.get("K", k))
 ClusterBatch.tile_vec = int(os.environ.get("VEC", "0")) or None
