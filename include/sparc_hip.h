@@ -118,7 +118,7 @@ size_t sparc_lap_workspace_bytes(int64_t m, int k, int ntiles);
  * src/utils.py builds from a 0/1 adjacency: A + I, D^-1 (A + I), with or without the diagonal enhancement):
  * there are no in-window weight streams; padding entries of s_addr point at the row behind the window
  * (s_addr = window rows * 64 vec), o_val is 1 for an entry and 0 for padding, and row_scale holds per row
- * r, delta = A[i][i] - r (0 without a stored diagonal) and delta / r.
+ * r, delta = A[i][i] - r (0 without a stored diagonal), delta / r and 1 / r.
  * a descriptor with slot_begin == slot_end is an empty workgroup (padding that lets a caller place
  * the workgroups of one window on one XCD: workgroup b runs on XCD b % 8).  kp (a multiple of hw,
  * >= k) is the padded number of columns per half; rows = the largest window, rows * 64 * vec <=
@@ -137,7 +137,7 @@ typedef struct sparc_tiling {
     const int32_t* o_row;
     const float* o_val;
     const float* o_valT;
-    const float* row_scale; /* device float[m][4] = {r, delta, delta / r, 0}: pattern mode (s_val == NULL), else NULL */
+    const float* row_scale; /* device float[m][4] = {r, delta, delta / r, 1 / r}: pattern mode (s_val == NULL), else NULL */
 } sparc_tiling_t;
 #define SPARC_TILE_LONG_ROW 128
 #define SPARC_TILE_MAX_RECORDS 512

@@ -42,7 +42,7 @@ struct SpmmArgs {
     const int32_t* o_row;
     const float* o_val;
     const float* o_valT;
-    const float* rowpat;  // pattern mode of the windowed kernel: float[m][4] = {r, delta, delta / r, 0}, else null
+    const float* rowpat;  // pattern mode of the windowed kernel: float[m][4] = {r, delta, delta / r, 1 / r}, else null
     int ndesc;
     int tile_rows;   // largest window (rows) over all descriptors
     int vec;         // floats per lane: a slab row is 16 * vec floats

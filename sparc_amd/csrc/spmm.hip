@@ -465,7 +465,7 @@ __device__ __forceinline__ void outside_chunk(float (&acc0)[VEC], float (&acc1)[
 //     (A x)_i = r_i sum_j x_j + delta_i x_i,      (A^T x)_i = sum_j (r_j x_j) + delta_i x_i,      delta_i = A[i][i] - r_i
 // (sums over the stored pattern of row i).  The gathered operand then carries the A^T half pre-multiplied by r
 // (the epilogue writes it that way), the gather is a plain sum of operand rows (no weight streams, no
-// weight broadcasts), and the row factors come back in the epilogue (a.rowpat: {r, delta, delta / r, 0} per row).
+// weight broadcasts), and the row factors come back in the epilogue (a.rowpat: {r, delta, delta / r, 1 / r} per row).
 // Padding entries of the in-window stream point at one extra, zeroed window row; outside entries keep a 0/1 weight.
 template <int VEC, bool DUAL, int EPI, int WM>
 __global__ __launch_bounds__(WIN_MAX_THREADS) void spmm_win(const SpmmArgs a) {
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(WIN_MAX_THREADS) void spmm_win(const SpmmArgs a) {
         Chunk4 c0;  // the first in-window chunk: all of a short row
         Chunk o0;   // the first outside chunk
         float x0[VEC];  // the row's own operand of the epilogue
-        float4 rp;      // pattern mode: {r, delta, delta / r, 0} of the row
+        float4 rp;      // pattern mode: {r, delta, delta / r, 1 / r} of the row
     };
     const bool has_out = d[6] != 0;  // any of this workgroup's rows has entries outside the window
     const unsigned lane4 = (lr * 4 + g) * 4, lane1 = lr * 4 + g;  // this lane's place inside a chunk of either stream
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(WIN_MAX_THREADS) void spmm_win(const SpmmArgs a) {
             pre.rc1 = *reinterpret_cast<const float4*>(a.rowc + row * SPARC_ROWC + 4);
         }
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) pre.x0[q] = cur.x0[q];
+        for (int q = 0; q < VEC; ++q) pre.x0[q] = (PAT && right) ? cur.x0[q] * cur.rp.w : cur.x0[q];   // stored times r: back to its own scale
         float acc[VEC], acc1[VEC];
 #pragma unroll
         for (int q = 0; q < VEC; ++q) acc[q] = acc1[q] = 0.f;
@@ -661,7 +661,7 @@ template <int KP, bool DUAL>
 __global__ __launch_bounds__(256) void lap_scale(int64_t m, int k, int64_t ldy, const float* __restrict__ Y,
                                                  const float* __restrict__ rowc, float* __restrict__ X, int hw, int rw,
                                                  int64_t plane, float* __restrict__ colpart, int64_t rows_per_block,
-                                                 float* __restrict__ G, const float* __restrict__ rowpat) {
+                                                 const float* __restrict__ rowpat) {
     constexpr int RG = 256 / KP;
     constexpr int NS = DUAL ? 6 : 3;
     const int col = threadIdx.x % KP, rg = threadIdx.x / KP;
@@ -676,14 +676,14 @@ __global__ __launch_bounds__(256) void lap_scale(int64_t m, int k, int64_t ldy, 
             const float4 rc1 = *reinterpret_cast<const float4*>(rowc + r * SPARC_ROWC + 4);
             const float y = (col < k) ? Y[r * ldy + col] * rc0.w : 0.f;
             X[xoff + r * rw] = y;
-            if (G) G[xoff + r * rw] = y;   // pattern mode: the first gathered operand, A^T half times the row factor
             s[0] += y;
             s[1] += rc1.z * y;
             s[2] += rc1.w * y;
             if (DUAL) {
                 const float x2 = y * fabsf(rc0.x);
-                X[xoff + r * rw + hw] = x2;
-                if (G) G[xoff + r * rw + hw] = x2 * rowpat[r * 4];
+                // pattern mode of the windowed kernel: the A^T half is kept multiplied by the row factor, in X as in
+                // every later operand of the chain (the epilogues divide the own-row operand back)
+                X[xoff + r * rw + hw] = rowpat ? x2 * rowpat[r * 4] : x2;
                 s[3] += x2;
                 s[4] += rc1.x * x2;
                 s[5] += rc1.y * x2;
@@ -1048,16 +1048,14 @@ int lap_fwd_impl(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* c
     const int rw = tiled ? 16 * tiling->vec : W;
     const int64_t plane = tiled ? a.plane : 0;
 
-    // pattern mode: the first pass gathers G0 = [X_A | r X_T], kept in P2 until the second pass overwrites it
-    float* G0 = a.rowpat ? P2 : nullptr;
     const dim3 gs(static_cast<unsigned>(p.nscale)), bs(256);
 #define SPARC_SCALE(KP)                                                                                              \
     if (dual)                                                                                                        \
         hipLaunchKernelGGL((lap_scale<KP, true>), gs, bs, 0, stream, m, k, ldy, Y, rowc, X, hw, rw, plane, colpart,   \
-                           p.rows_per_block, G0, a.rowpat);                                                                        \
+                           p.rows_per_block, a.rowpat);                                                                        \
     else                                                                                                             \
         hipLaunchKernelGGL((lap_scale<KP, false>), gs, bs, 0, stream, m, k, ldy, Y, rowc, X, hw, rw, plane, colpart,  \
-                           p.rows_per_block, G0, a.rowpat);
+                           p.rows_per_block, a.rowpat);
     if (kp == 16) { SPARC_SCALE(16) } else if (kp == 32) { SPARC_SCALE(32) } else if (kp == 48) { SPARC_SCALE(48) } else { SPARC_SCALE(64) }
 #undef SPARC_SCALE
     SPARC_CHECK_LAUNCH();
@@ -1071,7 +1069,7 @@ int lap_fwd_impl(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* c
     // (plus the own-row operand), then the row kernel over the remaining entries, which adds its gathers to it.
     {
         Timed both(EPI_ADD_X0, stream, 2);   // the two inner passes, back to back
-        a.Xg = G0 ? G0 : X; a.out = P1;
+        a.Xg = X; a.out = P1;
         if (blocks) {
             bl.Xg = X; bl.X0 = X; bl.out = P1;
             if ((rcode = sparc_blocks_launch(bl, true, fuse, stream))) return rcode;

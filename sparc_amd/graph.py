@@ -401,7 +401,7 @@ class ClusterBatch:
     use_pattern = True   # class-wide switch: weight-free gathers for supports whose off-diagonal values are row factors
 
     def row_factors(self):
-        """float32 [m, 4] = {r, delta, delta / r, 0} when every off-diagonal value of the support is its row's
+        """float32 [m, 4] = {r, delta, delta / r, 1 / r} when every off-diagonal value of the support is its row's
         factor, A[i][j] = r_i (and the mirrored value therefore r_j): the supports src/utils.py builds from a 0/1
         adjacency (A + I, D^-1 (A + I), with or without the diagonal enhancement); delta_i = A[i][i] - r_i (0 without
         a stored diagonal).  None otherwise.  Checked exactly, once per batch."""
@@ -434,7 +434,7 @@ class ClusterBatch:
         if bool((valT[off] != r[col[off]]).any()) or bool((valT[~off] != self.val[~off]).any()):
             return False
         delta = torch.where(has_diag, diag - r, torch.zeros_like(r))
-        return torch.stack([r, delta, delta / r, torch.zeros_like(r)], dim=1).contiguous()
+        return torch.stack([r, delta, delta / r, 1.0 / r], dim=1).contiguous()
 
     def _plan(self, vec, kp, n_slabs, dual, threads, target, mirrored=False, pattern=False):
         """Tiling for one kernel geometry: work descriptors and slot records (planned on the host) and the
