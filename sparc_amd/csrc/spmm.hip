@@ -662,47 +662,80 @@ __global__ __launch_bounds__(256) void lap_scale(int64_t m, int k, int64_t ldy, 
                                                  const float* __restrict__ rowc, float* __restrict__ X, int hw, int rw,
                                                  int64_t plane, float* __restrict__ colpart, int64_t rows_per_block,
                                                  const float* __restrict__ rowpat) {
-    constexpr int RG = 256 / KP;
+    // a thread owns four consecutive columns (hw is a multiple of 4: they share a slab) of every RG-th row:
+    // 16-byte stores into the slab-major operand
+    constexpr int TPR = KP / 4;         // threads per row
+    constexpr int RG = 256 / TPR;       // rows per sweep of the workgroup
     constexpr int NS = DUAL ? 6 : 3;
-    const int col = threadIdx.x % KP, rg = threadIdx.x / KP;
+    const int c4 = (threadIdx.x % TPR) * 4, rg = threadIdx.x / TPR;
     const int64_t base = blockIdx.x * rows_per_block;
     const int64_t end = min(m, base + rows_per_block);
-    const int64_t xoff = static_cast<int64_t>(col / hw) * plane + col % hw;
-    float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int64_t xoff = static_cast<int64_t>(c4 / hw) * plane + c4 % hw;
+    float s[6][4];
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s[q][u] = 0.f;
     if (rg < RG) {
-#pragma unroll 4
-        for (int64_t r = base + rg; r < end; r += RG) {
-            const float4 rc0 = *reinterpret_cast<const float4*>(rowc + r * SPARC_ROWC);
-            const float4 rc1 = *reinterpret_cast<const float4*>(rowc + r * SPARC_ROWC + 4);
-            const float y = (col < k) ? Y[r * ldy + col] * rc0.w : 0.f;
-            X[xoff + r * rw] = y;
-            s[0] += y;
-            s[1] += rc1.z * y;
-            s[2] += rc1.w * y;
-            if (DUAL) {
-                const float x2 = y * fabsf(rc0.x);
-                // pattern mode of the windowed kernel: the A^T half is kept multiplied by the row factor, in X as in
-                // every later operand of the chain (the epilogues divide the own-row operand back)
-                X[xoff + r * rw + hw] = rowpat ? x2 * rowpat[r * 4] : x2;
-                s[3] += x2;
-                s[4] += rc1.x * x2;
-                s[5] += rc1.y * x2;
+        // the pass is latency bound: the loads of B rows are requested before the first of them is used
+        constexpr int B = 4;
+        for (int64_t r0 = base + rg; r0 < end; r0 += B * RG) {
+            float4 rc0[B], rc1[B];
+            float yv[B][4], rf[B];
+#pragma unroll
+            for (int j = 0; j < B; ++j) {
+                const int64_t r = min(r0 + j * RG, end - 1);   // (rows past the end re-read the last row and are skipped below)
+                rc0[j] = *reinterpret_cast<const float4*>(rowc + r * SPARC_ROWC);
+                rc1[j] = *reinterpret_cast<const float4*>(rowc + r * SPARC_ROWC + 4);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) yv[j][u] = (c4 + u < k) ? Y[r * ldy + c4 + u] : 0.f;
+                rf[j] = (DUAL && rowpat) ? rowpat[r * 4] : 1.f;
+            }
+#pragma unroll
+            for (int j = 0; j < B; ++j) {
+                const int64_t r = r0 + j * RG;
+                if (r >= end) break;
+                float y[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) y[u] = yv[j][u] * rc0[j].w;
+                *reinterpret_cast<float4*>(X + xoff + r * rw) = make_float4(y[0], y[1], y[2], y[3]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    s[0][u] += y[u];
+                    s[1][u] += rc1[j].z * y[u];
+                    s[2][u] += rc1[j].w * y[u];
+                }
+                if (DUAL) {
+                    // pattern mode of the windowed kernel: the A^T half is kept multiplied by the row factor, in X as
+                    // in every later operand of the chain (the epilogues divide the own-row operand back)
+                    const float irho = fabsf(rc0[j].x);
+                    float x2s[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float x2 = y[u] * irho;
+                        x2s[u] = x2 * rf[j];
+                        s[3][u] += x2;
+                        s[4][u] += rc1[j].x * x2;
+                        s[5][u] += rc1[j].y * x2;
+                    }
+                    *reinterpret_cast<float4*>(X + xoff + r * rw + hw) = make_float4(x2s[0], x2s[1], x2s[2], x2s[3]);
+                }
             }
         }
     }
     __shared__ float sm[RG][6][KP];
     if (rg < RG) {
 #pragma unroll
-        for (int q = 0; q < NS; ++q) sm[rg][q][col] = s[q];
+        for (int q = 0; q < NS; ++q)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sm[rg][q][c4 + u] = s[q][u];
     }
     __syncthreads();
-    if (rg == 0) {
-#pragma unroll
-        for (int q = 0; q < NS; ++q) {
-            float t = 0.f;
-            for (int j = 0; j < RG; ++j) t += sm[j][q][col];
-            colpart[(blockIdx.x * 6 + q) * KP + col] = t;
-        }
+    for (int e = threadIdx.x; e < NS * KP; e += 256) {  // fixed order over the row groups
+        const int q = e / KP, col = e % KP;
+        float t = 0.f;
+        for (int j = 0; j < RG; ++j) t += sm[j][q][col];
+        colpart[(blockIdx.x * 6 + q) * KP + col] = t;
     }
 }
 
@@ -961,7 +994,7 @@ extern "C" int sparc_spmm(int64_t m, int64_t nnz, const int64_t* rowptr, const i
 }
 
 namespace {
-constexpr int SCALE_MAX_BLOCKS = 256;
+constexpr int SCALE_MAX_BLOCKS = 128;
 // Columns per half: the windowed kernel takes multiples of 16, the row kernels 16, 32 or 64.
 int padded_k(int k, bool tiled) { return tiled ? (k + 15) / 16 * 16 : (k <= 16 ? 16 : (k <= 32 ? 32 : 64)); }
 
@@ -971,7 +1004,7 @@ struct LapPlan {
 };
 LapPlan lap_plan(int64_t m, int kp, int ntiles) {
     LapPlan p;
-    const int rg = 256 / kp;
+    const int rg = 256 / (kp / 4);   // rows per sweep of a lap_scale workgroup
     int64_t nb = (m + 63) / 64;
     if (nb > SCALE_MAX_BLOCKS) nb = SCALE_MAX_BLOCKS;
     if (nb < 1) nb = 1;
