@@ -861,7 +861,11 @@ int launch_win(const SpmmArgs& a, hipStream_t stream) {
     }();
     b.dbg = dbg;
     b.stamps = (dbg & 64) && EPI == EPI_ADD_X0 ? g_stamps : nullptr;
-    hipLaunchKernelGGL((spmm_win<VEC, DUAL, EPI, WM>), dim3(static_cast<unsigned>(a.ndesc)), dim3(a.threads), lds, stream, b);
+    // the fused-loss variants of the narrow lanes need more registers: eight waves per workgroup keep two
+    // workgroups on a CU (the plan does not depend on the width: a wave takes slots wave, wave + nwaves, ...)
+    const bool lap = EPI == EPI_LAP_SINGLE || EPI == EPI_LAP_DUAL;
+    const int threads = (lap && VEC == 2 && a.threads > 512) ? 512 : a.threads;
+    hipLaunchKernelGGL((spmm_win<VEC, DUAL, EPI, WM>), dim3(static_cast<unsigned>(a.ndesc)), dim3(threads), lds, stream, b);
     SPARC_CHECK_LAUNCH();
     return SPARC_OK;
 }

@@ -314,9 +314,11 @@ class ClusterBatch:
         if geo is None or self._measured.get((k, bool(training))) in ("rows", "blocks"):
             return None
         vec, kp, n_slabs = geo
-        threads = self.tile_threads or (512 if vec == 2 else 1024)
-        target = self.tile_target_wgs or (2 * N_CU if vec == 2 else N_CU)
         pattern = self.use_pattern and self.row_factors() is not None
+        # a 512-row window is 64 KB at vec 2: two workgroups per CU; the weight-free training kernel needs 80
+        # registers, so twelve waves per workgroup (six per SIMD) fit
+        threads = self.tile_threads or ((768 if pattern and training else 512) if vec == 2 else 1024)
+        target = self.tile_target_wgs or (2 * N_CU if vec == 2 else N_CU)
         key = (vec, kp, bool(training), threads, target, pattern)
         if key not in self._tiles:
             self._tiles[key] = self._plan(vec, kp, n_slabs, bool(training), threads, target, pattern=pattern)
