@@ -274,7 +274,7 @@ class ClusterBatch:
                 wb[a:b] = a
                 we[a:b] = b
             p0, p1 = self.rowptr[:-1], self.rowptr[1:]
-            rows = torch.repeat_interleave(torch.arange(m, device=dev), p1 - p0)
+            rows = torch.repeat_interleave(torch.arange(m, device=dev), p1 - p0, output_size=self.nnz)
             keys = rows * m + self.colidx.to(torch.int64)        # ascending: CSR order
             base = torch.arange(m, device=dev, dtype=torch.int64) * m
             lo = torch.searchsorted(keys, base + wb)
@@ -361,7 +361,7 @@ class ClusterBatch:
         start = np.concatenate([[0], np.cumsum(sizes)])
         cl_of = torch.from_numpy(np.repeat(np.arange(len(sizes)), sizes)).to(dev)
         counts = self.rowptr[1:] - self.rowptr[:-1]
-        row = torch.repeat_interleave(torch.arange(m, device=dev), counts)
+        row = torch.repeat_interleave(torch.arange(m, device=dev), counts, output_size=self.nnz)
         col = self.colidx.to(torch.int64)
         same = cl_of[row] == cl_of[col]
         fill = float(same.sum()) / float((sizes.astype(np.float64) ** 2).sum())
@@ -416,7 +416,7 @@ class ClusterBatch:
             return False
         dev, m = self.device, self.m
         counts = self.rowptr[1:] - self.rowptr[:-1]
-        row = torch.repeat_interleave(torch.arange(m, device=dev), counts)
+        row = torch.repeat_interleave(torch.arange(m, device=dev), counts, output_size=self.nnz)
         col = self.colidx.to(torch.int64)
         off = row != col
         inf = torch.full((m,), float("inf"), dtype=torch.float32, device=dev)
@@ -471,7 +471,7 @@ class ClusterBatch:
         r_base, r_obase = up(pl["slot_base"][pl["row_slot"]]), up(pl["slot_obase"][pl["row_slot"]])
         r_g, r_long, r_w0 = up(pl["row_g"]), up(pl["row_long"]).bool(), up(wb)
         counts = self.rowptr[1:] - self.rowptr[:-1]
-        row = torch.repeat_interleave(torch.arange(m, device=dev), counts)
+        row = torch.repeat_interleave(torch.arange(m, device=dev), counts, output_size=self.nnz)
         e = torch.arange(self.nnz, device=dev, dtype=torch.int64) - r_p0[row]
         ein = e - r_nb[row]
         inside = (ein >= 0) & (ein < r_ni[row])
@@ -497,7 +497,7 @@ class ClusterBatch:
             first = np.maximum(pl["slot_rows"][:, 0], 0)
             pad = up(we[first] * (64 * vec))
             if len(pl["slot_L"]):
-                s_addr[:pl["stream_len"]] = torch.repeat_interleave(pad, up(pl["slot_L"] * 16)).to(torch.int32)
+                s_addr[:pl["stream_len"]] = torch.repeat_interleave(pad, up(pl["slot_L"] * 16), output_size=int(pl["stream_len"])).to(torch.int32)
             s_addr[pi] = ((col[inside] - r_w0[row[inside]]) * (64 * vec)).to(torch.int32)
             o_val[po] = 1.0
             rf = self.row_factors()
