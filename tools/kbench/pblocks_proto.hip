@@ -1,0 +1,384 @@
+// Prototype of a chain pass in row-factor form on the matrix cores (gfx950): the in-cluster part of
+//     out_i = r_i * sum_{j in pattern(i)} x_j + delta_i * x_i + x0_i          (A half;  the A^T half likewise, operand times r)
+// as a product of the cluster's 0/1 pattern (a bitmap, expanded to bf16 in registers) with the fp32 operand split
+// exactly into three bf16 pieces (x = hi + mid + lo: every product is exact, the sums are fp32), so the result is an
+// fp32 sum in another order.  Unit of work = (cluster, 16 operand columns, part of the cluster's rows): the unit
+// stages all operand rows of the cluster for its columns (split into three [k][16] bf16 planes in LDS), each wave
+// multiplies RT row tiles of 16 rows with v_mfma_f32_16x16x32_bf16, B operands by transposed LDS reads.
+//   hipcc --offload-arch=gfx950 -O3 -o pblocks_proto pblocks_proto.hip && ./pblocks_proto [mode]
+// mode bits (ablation): 1 = no products, 2 = no staging, 4 = no epilogue stores; 32 = also time every launch behind
+// 300 us of matrix work (the clocks inside a training step).  Further arguments: clusters, rows per cluster, fill.
+// Measured (50 clusters of 490 rows, 32.8 entries per row, 96 operand columns): 13.5 us per pass in the best geometry
+// (8 waves x 2 row tiles), of which 6.3 us are the 461 k matrix instructions (two thirds of their peak rate: 600 units
+// over 256 CUs), 0.7 us the staging that does not hide behind them and 6.7 us launch, barriers and the epilogue.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <cmath>
+#include <vector>
+#include <random>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int RW = 32;            // floats per slab row: 16 columns of the A half, 16 of the A^T half
+constexpr int PLANE_ROW = 32;     // bytes per operand row in one bf16 plane (16 columns)
+
+struct Args {
+    const float* X;       // [slabs][m][RW]
+    const float* X0;
+    float* out;
+    const float* rowpat;  // [m][4] = {r, delta, delta / r, 1 / r}
+    const unsigned* bits; // per cluster: [row tile][k group of 128][lane]
+    const int* desc;      // per unit: {w0, P, column tile, first row tile of the part, bitmap offset (dwords), KP}
+    int64_t plane;        // floats per slab
+    int mode;
+};
+
+// byte offset of operand row k inside a plane: blocks of 8 rows (256 B), the two 4-row halves of odd blocks swapped,
+// so that the two 16-lane groups of a 32-lane half read different banks
+__device__ __forceinline__ int row_off(const int k) {
+    return 256 * (k >> 3) + 128 * (((k >> 2) & 1) ^ ((k >> 3) & 1)) + 32 * (k & 3);
+}
+
+__device__ __forceinline__ unsigned hi_pair(const float a, const float b) {   // bf16 truncations of a (low half) and b (high half)
+    return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+
+template <int WAVES, int RT>
+__global__ __launch_bounds__(WAVES * 64) void pblocks(const Args a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int* d = a.desc + blockIdx.x * 8;
+    const int w0 = d[0], P = d[1], ct = d[2], tile0 = d[3], boff = d[4], KP = d[5];
+    if (P == 0) return;   // padding unit
+    const int slab = ct >> 1, half = ct & 1;
+    const int plane_bytes = KP * PLANE_ROW;
+    const int NG = KP >> 7;
+    const float* Xs = a.X + slab * a.plane + static_cast<int64_t>(w0) * RW + half * 16;
+
+    // the pattern bits of this wave's row tiles
+    unsigned dw[RT][4];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int G = 0; G < 4; ++G) {
+            const int tile = tile0 + wave * RT + rt;
+            dw[rt][G] = (G < NG && tile * 16 < P) ? a.bits[boff + (tile * NG + G) * 64 + lane] : 0u;
+        }
+
+    // operand rows travel in chunks of 128 rows: chunk G + 1 is requested before the products of chunk G and
+    // split into its three bf16 planes behind them
+    constexpr int NT = WAVES * 64;
+    constexpr int CL = (512 + NT - 1) / NT;   // float4 loads per thread and chunk
+    float4 v[CL];
+    auto request = [&](const int G) {
+#pragma unroll
+        for (int u = 0; u < CL; ++u) {
+            const int idx = u * NT + tid;
+            const int k = G * 128 + (idx >> 2), qd = idx & 3;
+            v[u] = (idx < 512 && k < P && !(a.mode & 2)) ? *reinterpret_cast<const float4*>(Xs + k * RW + qd * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto split_store = [&](const int G) {
+#pragma unroll
+        for (int u = 0; u < CL; ++u) {
+            const int idx = u * NT + tid;
+            if (idx < 512) {
+                const int k = G * 128 + (idx >> 2), qd = idx & 3;
+                const float x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                float r1[4], r2[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    r1[i] = x[i] - __uint_as_float(__float_as_uint(x[i]) & 0xffff0000u);
+                    r2[i] = r1[i] - __uint_as_float(__float_as_uint(r1[i]) & 0xffff0000u);
+                }
+                char* p = lds + row_off(k) + qd * 8;
+                *reinterpret_cast<uint2*>(p) = make_uint2(hi_pair(x[0], x[1]), hi_pair(x[2], x[3]));
+                *reinterpret_cast<uint2*>(p + plane_bytes) = make_uint2(hi_pair(r1[0], r1[1]), hi_pair(r1[2], r1[3]));
+                *reinterpret_cast<uint2*>(p + 2 * plane_bytes) = make_uint2(hi_pair(r2[0], r2[1]), hi_pair(r2[2], r2[3]));
+            }
+        }
+    };
+    request(0);
+    split_store(0);
+
+    f32x4 acc[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int g = lane >> 4, q = (lane & 15) >> 2, p4 = lane & 3;
+    const int lbase = static_cast<int>(reinterpret_cast<uintptr_t>(lds)) + 256 * g + 32 * q + 8 * p4;
+    const int a0 = lbase + 128 * (g & 1), a1 = lbase + 128 * (1 - (g & 1));
+#pragma unroll
+    for (int G = 0; G < 4; ++G) {   // unrolled: the pattern words of a chunk are named registers
+        if (G >= NG) break;
+        if (G + 1 < NG) request(G + 1);
+        __syncthreads();   // chunk G is in LDS
+        if (!(a.mode & 1)) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int koff = (G * 4 + s4) * 1024;
+                bf16x8 b[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    struct { s16x4 x, y; } bb;
+                    bb.x = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(uintptr_t)(a0 + koff + pl * plane_bytes));
+                    bb.y = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(uintptr_t)(a1 + koff + pl * plane_bytes));
+                    b[pl] = __builtin_bit_cast(bf16x8, bb);
+                }
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const unsigned w = dw[rt][G];
+                    u32x4 au;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 4 * s4 + r;   // bit i: element 2r, bit i + 16: element 2r + 1
+                        au[r] = (i < 15 ? (w << (14 - i)) : (w >> 1)) & 0x40004000u;   // bf16 2.0 = 0x4000
+
+                    }
+                    const bf16x8 av = __builtin_bit_cast(bf16x8, au);
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b[pl], acc[rt], 0, 0, 0);
+                }
+            }
+        }
+        if (G + 1 < NG) split_store(G + 1);
+    }
+
+    // epilogue in row layout: lane = (row lane >> 2 of the tile, columns 4 (lane & 3) ...); the row's own operand comes
+    // back from the three planes (their sum is exact), the products through a per-wave transposition in LDS
+    const int er = lane >> 2, eq = lane & 3;
+    float4 own[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int rl = (tile0 + wave * RT + rt) * 16 + er;
+        const char* p = lds + row_off(rl < KP ? rl : 0) + eq * 8;
+        const uint2 h = *reinterpret_cast<const uint2*>(p), mm = *reinterpret_cast<const uint2*>(p + plane_bytes),
+                    lo = *reinterpret_cast<const uint2*>(p + 2 * plane_bytes);
+        auto lo3 = [](unsigned a_, unsigned b_, unsigned c_) { return (__uint_as_float(a_ << 16) + __uint_as_float(b_ << 16)) + __uint_as_float(c_ << 16); };
+        auto hi3 = [](unsigned a_, unsigned b_, unsigned c_) {
+            return (__uint_as_float(a_ & 0xffff0000u) + __uint_as_float(b_ & 0xffff0000u)) + __uint_as_float(c_ & 0xffff0000u);
+        };
+        own[rt] = make_float4(lo3(h.x, mm.x, lo.x), hi3(h.x, mm.x, lo.x), lo3(h.y, mm.y, lo.y), hi3(h.y, mm.y, lo.y));
+    }
+    __syncthreads();   // nobody reads the planes any more: their memory is the transposition scratch
+    float* scratch = reinterpret_cast<float*>(lds) + wave * (RT * 256);
+    const bool right = half != 0;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) scratch[rt * 256 + (4 * g + reg) * 16 + (lane & 15)] = acc[rt][reg];
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int rl = (tile0 + wave * RT + rt) * 16 + er;
+        const float4 t = *reinterpret_cast<const float4*>(scratch + rt * 256 + er * 16 + eq * 4);
+        if (rl < P) {
+            const int64_t row = w0 + rl;
+            const float4 rp = *reinterpret_cast<const float4*>(a.rowpat + row * 4);
+            const int64_t at = slab * a.plane + row * RW + half * 16 + eq * 4;
+            const float4 x0 = *reinterpret_cast<const float4*>(a.X0 + at);
+            const float tv[4] = {t.x, t.y, t.z, t.w}, ov[4] = {own[rt].x, own[rt].y, own[rt].z, own[rt].w}, xv[4] = {x0.x, x0.y, x0.z, x0.w};
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float vv = 0.5f * tv[e];
+                o[e] = right ? (fmaf(rp.z, ov[e], vv) + xv[e] * rp.w) * rp.x : fmaf(rp.x, vv, rp.y * ov[e]) + xv[e];
+            }
+            if (!(a.mode & 4)) *reinterpret_cast<float4*>(a.out + at) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+// keeps the matrix cores busy between two timed launches, as the GEMMs of a training step do (clocks of an idle chip
+// are lower than those the kernel sees inside a step)
+__global__ __launch_bounds__(256) void heater(float* out, int iters) {
+    bf16x8 x = __builtin_bit_cast(bf16x8, u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
+    for (int i = 0; i < iters; ++i) {
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, x, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, x, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, x, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, x, c3, 0, 0, 0);
+    }
+    if (c0[0] + c1[0] + c2[0] + c3[0] == 12345.f) out[threadIdx.x] = c0[1];
+}
+static bool g_heat = false;
+
+template <int WAVES, int RT>
+static void run(const char* name, const Args& a, int units, int lds_bytes, hipStream_t st, int reps, double alg_bytes) {
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pblocks<WAVES, RT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 50; ++i) hipLaunchKernelGGL((pblocks<WAVES, RT>), dim3(units), dim3(WAVES * 64), lds_bytes, st, a);
+    CK(hipStreamSynchronize(st));
+    CK(hipEventRecord(e0, st));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((pblocks<WAVES, RT>), dim3(units), dim3(WAVES * 64), lds_bytes, st, a);
+    CK(hipEventRecord(e1, st));
+    CK(hipStreamSynchronize(st));
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    if (g_heat) {   // every timed launch behind 300 us of matrix work
+        std::vector<hipEvent_t> ev(2 * reps);
+        for (auto& e : ev) CK(hipEventCreate(&e));
+        for (int i = 0; i < reps; ++i) {
+            hipLaunchKernelGGL(heater, dim3(1024), dim3(256), 0, st, a.out, 2000);
+            CK(hipEventRecord(ev[2 * i], st));
+            hipLaunchKernelGGL((pblocks<WAVES, RT>), dim3(units), dim3(WAVES * 64), lds_bytes, st, a);
+            CK(hipEventRecord(ev[2 * i + 1], st));
+        }
+        CK(hipStreamSynchronize(st));
+        double tot = 0.0;
+        for (int i = 0; i < reps; ++i) { float t; CK(hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1])); tot += t; }
+        for (auto& e : ev) CK(hipEventDestroy(e));
+        printf("   behind matrix work: %.2f us per launch (event pair per launch); ", tot * 1e3 / reps);
+    }
+    printf("%s: %d units x %d threads, LDS %d B: %.2f us per launch (%.2f TB/s of %.1f MB)\n", name, units, WAVES * 64, lds_bytes,
+           ms * 1e3 / reps, alg_bytes / (ms * 1e-3 / reps) / 1e12, alg_bytes / 1e6);
+}
+
+int main(int argc, char** argv) {
+    const int mode = argc > 1 ? atoi(argv[1]) & 7 : 0;
+    g_heat = argc > 1 && (atoi(argv[1]) & 32);
+    const int NC = argc > 2 ? atoi(argv[2]) : 50, P = argc > 3 ? atoi(argv[3]) : 490, NSLAB = 3;
+    const double fill = argc > 4 ? atof(argv[4]) : 0.065;
+    const int KP = (P + 127) / 128 * 128, NG = KP / 128, NT = (P + 15) / 16;
+    const int64_t m = static_cast<int64_t>(NC) * P, plane = m * RW;
+    std::mt19937 rng(1);
+    std::uniform_real_distribution<float> uf(-1.f, 1.f);
+    std::vector<float> X(NSLAB * plane), X0(NSLAB * plane), rowpat(m * 4);
+    for (auto& v : X) v = uf(rng);
+    for (auto& v : X0) v = uf(rng);
+    for (int64_t i = 0; i < m; ++i) {
+        const float r = 0.02f + 0.05f * (uf(rng) + 1.f), dl = 0.3f * uf(rng);
+        rowpat[i * 4] = r; rowpat[i * 4 + 1] = dl; rowpat[i * 4 + 2] = dl / r; rowpat[i * 4 + 3] = 1.f / r;
+    }
+    // symmetric 0/1 pattern per cluster, with diagonal
+    std::vector<uint8_t> pat(static_cast<size_t>(NC) * P * P, 0);
+    std::uniform_real_distribution<double> ud(0.0, 1.0);
+    size_t nnz = 0;
+    for (int c = 0; c < NC; ++c) {
+        uint8_t* A = pat.data() + static_cast<size_t>(c) * P * P;
+        for (int i = 0; i < P; ++i) {
+            A[i * P + i] = 1;
+            for (int j = i + 1; j < P; ++j)
+                if (ud(rng) < fill) A[i * P + j] = A[j * P + i] = 1;
+        }
+        for (int i = 0; i < P * P; ++i) nnz += A[i];
+    }
+    // bitmap: lane l of (row tile, k group G): row = 16 tile + (l & 15), k block = l >> 4; bit 4 s + r holds element 2r,
+    // bit 4 s + r + 16 element 2r + 1 of k = 128 G + 32 s + 8 (l >> 4) + ...
+    const int bits_per_cluster = NT * NG * 64;
+    std::vector<unsigned> bits(static_cast<size_t>(NC) * bits_per_cluster, 0u);
+    for (int c = 0; c < NC; ++c) {
+        const uint8_t* A = pat.data() + static_cast<size_t>(c) * P * P;
+        for (int t = 0; t < NT; ++t)
+            for (int G = 0; G < NG; ++G)
+                for (int l = 0; l < 64; ++l) {
+                    const int row = 16 * t + (l & 15);
+                    unsigned w = 0;
+                    if (row < P)
+                        for (int s = 0; s < 4; ++s)
+                            for (int r = 0; r < 4; ++r)
+                                for (int e = 0; e < 2; ++e) {
+                                    const int k = 128 * G + 32 * s + 8 * (l >> 4) + 2 * r + e;
+                                    if (k < P && A[row * P + k]) w |= 1u << (4 * s + r + 16 * e);
+                                }
+                    bits[static_cast<size_t>(c) * bits_per_cluster + (t * NG + G) * 64 + l] = w;
+                }
+    }
+    float *dX, *dX0, *dout, *drp; unsigned* dbits; int* ddesc;
+    CK(hipMalloc(&dX, X.size() * 4)); CK(hipMalloc(&dX0, X.size() * 4)); CK(hipMalloc(&dout, X.size() * 4));
+    CK(hipMalloc(&drp, rowpat.size() * 4)); CK(hipMalloc(&dbits, bits.size() * 4));
+    CK(hipMemcpy(dX, X.data(), X.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dX0, X0.data(), X.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(drp, rowpat.data(), rowpat.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dbits, bits.data(), bits.size() * 4, hipMemcpyHostToDevice));
+    hipStream_t st; CK(hipStreamCreate(&st));
+    const double alg = nnz * 12.0 + 8.0 * m + 3.0 * m * 94 * 4;   // the accounting of the windowed kernel at k = 47
+    printf("m = %lld, %zu pattern entries (%.1f per row), bitmap %.2f MB\n", (long long)m, nnz, double(nnz) / m, bits.size() * 4 / 1e6);
+
+    auto make_desc = [&](int rows_per_unit, std::vector<int>& desc) {
+        // workgroup b runs on XCD b % 8: all units of a cluster go to one XCD (cluster c -> XCD c % 8), so that the
+        // cluster's operand rows are fetched into one L2 only; XCDs with fewer units get padding units
+        const int tiles_per_unit = rows_per_unit / 16;
+        std::vector<std::vector<int>> per(8);
+        for (int c = 0; c < NC; ++c)
+            for (int ct = 0; ct < 2 * NSLAB; ++ct)
+                for (int t0 = 0; t0 < NT; t0 += tiles_per_unit) {
+                    const int dsc[8] = {c * P, P, ct, t0, c * bits_per_cluster, KP, 0, 0};
+                    per[c % 8].insert(per[c % 8].end(), dsc, dsc + 8);
+                }
+        size_t longest = 0;
+        for (auto& v : per) longest = std::max(longest, v.size() / 8);
+        desc.assign(longest * 8 * 8, 0);
+        for (int x = 0; x < 8; ++x)
+            for (size_t j = 0; j < per[x].size() / 8; ++j)
+                for (int e = 0; e < 8; ++e) desc[(j * 8 + x) * 8 + e] = per[x][j * 8 + e];
+        return static_cast<int>(desc.size() / 8);
+    };
+    Args a{dX, dX0, dout, drp, dbits, nullptr, plane, mode};
+    std::vector<int> desc;
+    const int lds_bytes = 3 * KP * PLANE_ROW;
+    auto with_desc = [&](int rows_per_unit) {
+        const int units = make_desc(rows_per_unit, desc);
+        if (ddesc) CK(hipFree(ddesc));
+        CK(hipMalloc(&ddesc, desc.size() * 4));
+        CK(hipMemcpy(ddesc, desc.data(), desc.size() * 4, hipMemcpyHostToDevice));
+        a.desc = ddesc;
+        return units;
+    };
+    ddesc = nullptr;
+    int units = with_desc(128);
+    // correctness of the first configuration against a double sum
+    CK(hipMemset(dout, 0, X.size() * 4));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pblocks<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipLaunchKernelGGL((pblocks<4, 2>), dim3(units), dim3(256), lds_bytes, st, a);
+    CK(hipStreamSynchronize(st));
+    std::vector<float> out(X.size());
+    CK(hipMemcpy(out.data(), dout, X.size() * 4, hipMemcpyDeviceToHost));
+    if (mode == 0) {
+        double worst = 0.0, worst32 = 0.0;
+        for (int c : {0, NC / 2, NC - 1}) {
+            const uint8_t* A = pat.data() + static_cast<size_t>(c) * P * P;
+            for (int i = 0; i < P; ++i) {
+                const int64_t row = static_cast<int64_t>(c) * P + i;
+                const float* rp = &rowpat[row * 4];
+                for (int s = 0; s < NSLAB; ++s)
+                    for (int cc = 0; cc < RW; ++cc) {
+                        double sum = 0.0; float sum32 = 0.f;
+                        for (int k = 0; k < P; ++k)
+                            if (A[i * P + k]) { sum += X[s * plane + (static_cast<int64_t>(c) * P + k) * RW + cc]; sum32 += X[s * plane + (static_cast<int64_t>(c) * P + k) * RW + cc]; }
+                        const int64_t at = s * plane + row * RW + cc;
+                        auto fin = [&](double sm) {
+                            return cc >= 16 ? (sm + double(rp[2]) * X[at] + double(X0[at]) * rp[3]) * rp[0]
+                                            : rp[0] * sm + double(rp[1]) * X[at] + X0[at];
+                        };
+                        const double ref = fin(sum);
+                        worst = std::max(worst, std::fabs(out[at] - ref) / (1.0 + std::fabs(ref)));
+                        worst32 = std::max(worst32, std::fabs(fin(sum32) - ref) / (1.0 + std::fabs(ref)));
+                    }
+            }
+        }
+        printf("largest error against a double sum: %.3g (a sequential fp32 sum: %.3g)\n", worst, worst32);
+    }
+    const int reps = 200;
+    run<4, 2>("4 waves x 2 row tiles (128 rows per unit)", a, units, lds_bytes, st, reps, alg);
+    units = with_desc(256);
+    run<4, 4>("4 waves x 4 row tiles (256 rows per unit)", a, units, lds_bytes, st, reps, alg);
+    run<8, 2>("8 waves x 2 row tiles (256 rows per unit)", a, units, lds_bytes, st, reps, alg);
+    units = with_desc(512);
+    run<8, 4>("8 waves x 4 row tiles (512 rows per unit)", a, units, lds_bytes, st, reps, alg);
+    run<16, 2>("16 waves x 2 row tiles (512 rows per unit)", a, units, lds_bytes, st, reps, alg);
+    units = with_desc(64);
+    run<2, 2>("2 waves x 2 row tiles (64 rows per unit)", a, units, lds_bytes, st, reps, alg);
+    run<4, 1>("4 waves x 1 row tile (64 rows per unit)", a, units, lds_bytes, st, reps, alg);
+    return 0;
+}
