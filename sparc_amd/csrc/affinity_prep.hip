@@ -29,21 +29,29 @@ __global__ void rowsums(int64_t m, const int64_t* __restrict__ rowptr, const int
 }
 
 // S_ii = A_ii + (A^2)_ii + (A^3)_ii in float64 straight from the definition (closed walks of
-// length 1..3); A_li is read from row i's mirrored values (the pattern is symmetric).
-__global__ void diag_of_s(int64_t m, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                          const float* __restrict__ val, const float* __restrict__ valT, double* __restrict__ sdiag) {
-    const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+// length 1..3); A_li is read from row i's mirrored values (the pattern is symmetric).  One wavefront per
+// row: the walk i -> j is wave-uniform, the lanes share the entries of row j and each looks its l up in the
+// sorted row i; the lanes' partial sums are combined in a fixed order.
+__global__ __launch_bounds__(256) void diag_of_s(int64_t m, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                 const float* __restrict__ val, const float* __restrict__ valT,
+                                                 double* __restrict__ sdiag) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = blockIdx.x * 4LL + (threadIdx.x >> 6);
     if (i >= m) return;
     const int64_t b0 = rowptr[i], b1 = rowptr[i + 1];
     double w1 = 0.0, w2 = 0.0, w3 = 0.0;
-    for (int64_t p = b0; p < b1; ++p) {
+    for (int64_t p = b0 + lane; p < b1; p += 64) {
+        const double aij = val[p];
+        if (col[p] == i) w1 = aij;
+        w2 += aij * static_cast<double>(valT[p]);
+    }
+    for (int64_t p = b0; p < b1; ++p) {  // wave-uniform
         const int64_t j = col[p];
         const double aij = val[p];
-        if (j == i) w1 = aij;
-        w2 += aij * static_cast<double>(valT[p]);
         if (aij == 0.0) continue;
-        double inner = 0.0;  // sum_l A_jl A_li
-        for (int64_t q = rowptr[j]; q < rowptr[j + 1]; ++q) {
+        double inner = 0.0;  // this lane's share of sum_l A_jl A_li
+        const int64_t q1 = rowptr[j + 1];
+        for (int64_t q = rowptr[j] + lane; q < q1; q += 64) {
             const int32_t l = col[q];
             int64_t lo = b0, hi = b1;
             while (lo < hi) {
@@ -54,7 +62,8 @@ __global__ void diag_of_s(int64_t m, const int64_t* __restrict__ rowptr, const i
         }
         w3 += aij * inner;
     }
-    sdiag[i] = w1 + w2 + w3;
+    const double t = wave_sum(w1) + wave_sum(w2) + wave_sum(w3);
+    if (lane == 0) sdiag[i] = t;
 }
 
 // y = add + M x with M given by (rowptr, col, v); add may be null
@@ -251,7 +260,7 @@ extern "C" int sparc_affinity_prep(int64_t m, int64_t nnz, const int64_t* rowptr
 
     const dim3 bt(256), gt(static_cast<unsigned>((m + 255) / 256));
     hipLaunchKernelGGL(rowsums, gt, bt, 0, stream, m, rowptr, colidx, val, vT, r, c, iso);
-    hipLaunchKernelGGL(diag_of_s, gt, bt, 0, stream, m, rowptr, colidx, val, vT, sdiag);
+    hipLaunchKernelGGL(diag_of_s, dim3(static_cast<unsigned>((m + 3) / 4)), bt, 0, stream, m, rowptr, colidx, val, vT, sdiag);
     hipLaunchKernelGGL(spmv64, gt, bt, 0, stream, m, rowptr, colidx, val, r, static_cast<const double*>(nullptr), r2);
     hipLaunchKernelGGL(spmv64, gt, bt, 0, stream, m, rowptr, colidx, vT, c, static_cast<const double*>(nullptr), c2);
     hipLaunchKernelGGL(spmv64, gt, bt, 0, stream, m, rowptr, colidx, val, r2, static_cast<const double*>(nullptr), r3);
