@@ -126,22 +126,30 @@ __global__ __launch_bounds__(256) void prep_scalars(int64_t m, double eps, const
     }
 }
 
-// P1 = E_J + A[:, J]: lane l of the row's wave looks column col0 + l up in the sorted row.
+// P1 = E_J + A[:, J]: lane l of the row's wave looks column col0 + l up in the sorted row.  Rows without an
+// entry in these columns are flagged as zero instead of stored.
 __global__ __launch_bounds__(256) void build_p1(int64_t m, const int64_t* __restrict__ rowptr,
                                                 const int32_t* __restrict__ col, const float* __restrict__ val,
-                                                int64_t col0, float* __restrict__ P1) {
+                                                int64_t col0, float* __restrict__ P1, uint8_t* __restrict__ flag) {
     const int lane = threadIdx.x & 63;
     const int64_t row = blockIdx.x * 4LL + (threadIdx.x >> 6);
     if (row >= m) return;
     const int64_t target = col0 + lane;
     float out = (target == row) ? 1.f : 0.f;
-    int64_t lo = rowptr[row], hi = rowptr[row + 1];
-    while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (col[mid] < target) lo = mid + 1; else hi = mid;
+    const int64_t b0 = rowptr[row], b1 = rowptr[row + 1];
+    // the row's entries lie in [col[b0], col[b1 - 1]]: most rows miss the 64 columns altogether
+    const bool near = b1 > b0 && col[b0] < col0 + PREP_W && col[b1 - 1] >= col0;
+    if (near) {
+        int64_t lo = b0, hi = b1;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (col[mid] < target) lo = mid + 1; else hi = mid;
+        }
+        if (lo < b1 && col[lo] == target) out += val[lo];
     }
-    if (lo < rowptr[row + 1] && col[lo] == target) out += val[lo];
-    P1[row * PREP_W + lane] = out;
+    const bool nz = __any(out != 0.f);
+    if (nz) P1[row * PREP_W + lane] = out;
+    if (lane == 0) flag[row] = nz ? 1 : 0;
 }
 
 // rho, g, d and x = 1/rho from the accumulated row statistics.
@@ -219,7 +227,7 @@ struct PrepPlan {
 };
 size_t prep_bytes(int64_t m) {
     const size_t vd = sparc_align_up(static_cast<size_t>(m) * sizeof(double));
-    return 14 * vd + sparc_align_up(static_cast<size_t>(m) * 8 * sizeof(double)) +
+    return 14 * vd + 2 * sparc_align_up(static_cast<size_t>(m)) + sparc_align_up(static_cast<size_t>(m) * 8 * sizeof(double)) +
            2 * sparc_align_up(static_cast<size_t>(m) * PREP_W * sizeof(float)) + 2 * sparc_align_up(16 * sizeof(double));
 }
 
@@ -256,6 +264,8 @@ extern "C" int sparc_affinity_prep(int64_t m, int64_t nnz, const int64_t* rowptr
     float* P2 = cv.take<float>(static_cast<size_t>(m) * PREP_W);
     double* scal = cv.take<double>(16);
     double* utx = cv.take<double>(16);
+    uint8_t* flag1 = cv.take<uint8_t>(m);
+    uint8_t* flag2 = cv.take<uint8_t>(m);
     if (!ws || !cv.ok()) return SPARC_ERR_WS;
 
     const dim3 bt(256), gt(static_cast<unsigned>((m + 255) / 256));
@@ -273,12 +283,12 @@ extern "C" int sparc_affinity_prep(int64_t m, int64_t nnz, const int64_t* rowptr
     a.racc = racc; a.cvec = c; a.c2vec = c2;
     const dim3 gp(static_cast<unsigned>((m + 3) / 4));
     for (int64_t col0 = 0; col0 < m; col0 += PREP_W) {
-        hipLaunchKernelGGL(build_p1, gp, bt, 0, stream, m, rowptr, colidx, val, col0, P1);
+        hipLaunchKernelGGL(build_p1, gp, bt, 0, stream, m, rowptr, colidx, val, col0, P1, flag1);
         a.col0 = col0;
-        a.Xg = P1; a.out = P2;
+        a.Xg = P1; a.out = P2; a.gflag = flag1; a.oflag = flag2;
         int rc = sparc_spmm_launch(EPI_ADD_IDENT, PREP_W, a, stream);
         if (rc) return rc;
-        a.Xg = P2; a.out = nullptr;
+        a.Xg = P2; a.out = nullptr; a.gflag = flag2; a.oflag = nullptr;
         rc = sparc_spmm_launch(EPI_PREP_ACC, PREP_W, a, stream);
         if (rc) return rc;
     }

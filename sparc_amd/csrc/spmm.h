@@ -56,6 +56,8 @@ struct SpmmArgs {
     const double* cvec;
     const double* c2vec;
     int64_t col0;
+    const uint8_t* gflag;  // [m]: nonzero where the row of Xg holds anything (the other rows are not read)
+    uint8_t* oflag;        // [m]: EPI_ADD_IDENT writes it for out, and stores only the rows that hold anything
 };
 
 // LDS budget of one window

@@ -116,11 +116,17 @@ __device__ __forceinline__ void row_epilogue(const SpmmArgs& a, const int64_t ro
             store_vec<VEC>(outp, acc);
         }
     } else if (EPI == EPI_ADD_IDENT) {
+        bool nz = false;
         if (owner) {
 #pragma unroll
-            for (int q = 0; q < VEC; ++q) acc[q] += (colbase + q == row) ? 1.f : 0.f;
-            store_vec<VEC>(outp, acc);
+            for (int q = 0; q < VEC; ++q) {
+                acc[q] += (colbase + q == row) ? 1.f : 0.f;
+                nz |= acc[q] != 0.f;
+            }
         }
+        nz = __any(nz);   // a zero row is flagged instead of stored
+        if (owner && nz) store_vec<VEC>(outp, acc);
+        if (lane == 0) a.oflag[row] = nz ? 1 : 0;
     } else if (EPI == EPI_PREP_ACC) {
         // acc holds S[row, colbase .. colbase + VEC): gather the row statistics of S
         double ss = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0;
@@ -177,10 +183,11 @@ __device__ __forceinline__ void row_epilogue(const SpmmArgs& a, const int64_t ro
 }
 
 // ------------------------------------------------------------------ spmm_rows
-// U gathers in flight: the U rows of X are requested before the first is consumed.
-template <int LR, bool DUAL, int U>
+// U gathers in flight: the U rows of X are requested before the first is consumed.  FL: entries whose flag is
+// zero point at operand rows that are zero and are not read (their lanes take no part in the load).
+template <int LR, bool DUAL, int U, bool FL = false>
 __device__ __forceinline__ void gather_rows(float4& acc, const int c, const float v, const float vt, const int it,
-                                            const int g, const int lr, const float* __restrict__ Xg) {
+                                            const int g, const int lr, const float* __restrict__ Xg, const int f = 1) {
     constexpr int W = LR * 4, G = 64 / LR, HALF = LR / 2;
     float4 x[U];
     float w[U];
@@ -194,7 +201,12 @@ __device__ __forceinline__ void gather_rows(float4& acc, const int c, const floa
             vj = (lr >= HALF) ? vtj : vj;
         }
         w[u] = vj;
-        x[u] = *reinterpret_cast<const float4*>(Xg + static_cast<int64_t>(cj) * W + lr * 4);
+        if (FL) {
+            x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (__shfl(f, idx)) x[u] = *reinterpret_cast<const float4*>(Xg + static_cast<int64_t>(cj) * W + lr * 4);
+        } else {
+            x[u] = *reinterpret_cast<const float4*>(Xg + static_cast<int64_t>(cj) * W + lr * 4);
+        }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -214,27 +226,48 @@ __device__ __forceinline__ void wave_row_global(const SpmmArgs& a, const int64_t
     const int g = lane / LR, lr = lane % LR;
     const int64_t p0 = a.skip_entries ? 0 : a.rowptr[row], p1 = a.skip_entries ? 0 : a.rowptr[row + 1];
     const RowPre<4> pre = row_preload<4, EPI>(a, row, a.X0 ? a.X0 + row * W + lr * 4 : nullptr);
+    // the sweeps of the affinity preparation multiply operands whose rows are mostly zero: a byte per operand row
+    // says whether it holds anything, zero rows are neither stored nor read (the sums are the same bit for bit)
+    constexpr bool FL = EPI == EPI_ADD_IDENT || EPI == EPI_PREP_ACC;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool any_live = false;  // wave-uniform
     for (int64_t p = p0; p < p1; p += 64) {
         const int cnt = static_cast<int>(min(static_cast<int64_t>(64), p1 - p));
-        int c = 0;
+        int c = 0, f = 0;
         float v = 0.f, vt = 0.f;
         if (lane < cnt) {
             c = a.col[p + lane];
             v = a.val[p + lane];
             if (DUAL) vt = a.valT[p + lane];
+            if (FL) f = a.gflag[c];
         }
         // idle lanes point at a row that is read anyway and carry a zero weight
         const int c_first = __shfl(c, 0);
         if (lane >= cnt) c = c_first;
         const int iters = (cnt + G - 1) / G;  // wave-uniform; (iters - 1) * G + g <= 63
         int it = 0;
+        if (FL) {
+            const unsigned long long live = __ballot(f != 0);
+            if (live == 0ull) continue;
+            any_live = true;
+            auto has = [&](const int first, const int n) {  // any flagged entry in iterations [first, first + n)
+                return ((live >> (first * G)) & (n * G >= 64 ? ~0ull : ((1ull << (n * G)) - 1ull))) != 0ull;
+            };
+            if (G <= 8)
+                for (; it + 8 <= iters; it += 8)
+                    if (has(it, 8)) gather_rows<LR, DUAL, 8, true>(acc, c, v, vt, it, g, lr, a.Xg, f);
+            if (it + 4 <= iters) { if (has(it, 4)) gather_rows<LR, DUAL, 4, true>(acc, c, v, vt, it, g, lr, a.Xg, f); it += 4; }
+            if (it + 2 <= iters) { if (has(it, 2)) gather_rows<LR, DUAL, 2, true>(acc, c, v, vt, it, g, lr, a.Xg, f); it += 2; }
+            if (it < iters && has(it, 1)) gather_rows<LR, DUAL, 1, true>(acc, c, v, vt, it, g, lr, a.Xg, f);
+            continue;
+        }
         if (G <= 8)
             for (; it + 8 <= iters; it += 8) gather_rows<LR, DUAL, 8>(acc, c, v, vt, it, g, lr, a.Xg);
         if (it + 4 <= iters) { gather_rows<LR, DUAL, 4>(acc, c, v, vt, it, g, lr, a.Xg); it += 4; }
         if (it + 2 <= iters) { gather_rows<LR, DUAL, 2>(acc, c, v, vt, it, g, lr, a.Xg); it += 2; }
         if (it < iters) gather_rows<LR, DUAL, 1>(acc, c, v, vt, it, g, lr, a.Xg);
     }
+    if (EPI == EPI_PREP_ACC && !any_live) return;  // a zero row of S[:, J] adds nothing to the statistics
 #pragma unroll
     for (int off = LR; off < 64; off <<= 1) {
         acc.x += __shfl_xor(acc.x, off);
@@ -939,8 +972,8 @@ int sparc_spmm_launch(int epi, int width, const SpmmArgs& a, hipStream_t stream)
     switch (epi) {
         case EPI_STORE: return launch_single<EPI_STORE>(width, a, stream);
         case EPI_ADD_X0: return launch_single<EPI_ADD_X0>(width, a, stream);
-        case EPI_ADD_IDENT: return width == 64 && !a.desc ? launch_single<EPI_ADD_IDENT>(64, a, stream) : SPARC_ERR_ARG;
-        case EPI_PREP_ACC: return width == 64 && !a.desc ? launch_single<EPI_PREP_ACC>(64, a, stream) : SPARC_ERR_ARG;
+        case EPI_ADD_IDENT: return width == 64 && !a.desc && a.gflag && a.oflag ? launch_single<EPI_ADD_IDENT>(64, a, stream) : SPARC_ERR_ARG;
+        case EPI_PREP_ACC: return width == 64 && !a.desc && a.gflag ? launch_single<EPI_PREP_ACC>(64, a, stream) : SPARC_ERR_ARG;
     }
     return SPARC_ERR_ARG;
 }
