@@ -851,3 +851,48 @@ def test_hip_graph_steps_match_eager_steps(dev):
     assert np.all(np.isfinite(runs[True][0]))
     assert rel(runs[True][0], runs[False][0]) < 1e-5, (runs[True][0], runs[False][0])
     assert rel(runs[True][1], runs[False][1]) < 1e-5
+
+
+def test_training_separates_planted_clusters(dev, tmp_path, monkeypatch, capsys):
+    """End to end on a graph with a known answer: six planted clusters, every batch holds a share of each (the
+    reference's training input for num_clusters = 1, src/partition_utils.py:57-58), features that tell the clusters
+    apart only through noise.  After 150 epochs the loss has dropped and the embedding of unseen nodes (predict)
+    puts them next to their own cluster's centre: the step does what SpectralNet is for, not only what one reference
+    step computes."""
+    from sparc_amd.SpectralNet import SpectralNet
+    from sparc_amd.SpectralTrainer import SpectralTrainer
+    rng = np.random.default_rng(3)
+    ncl, per, din = 6, 180, 16
+    n = ncl * per
+    label = np.repeat(np.arange(ncl), per)
+    P = np.where(label[:, None] == label[None, :], 0.12, 0.002)
+    A = sp.csr_matrix(np.triu(rng.random((n, n)) < P, 1).astype(np.float64))
+    A = A + A.T + sp.eye(n)
+    centres = rng.normal(size=(ncl, din))
+    X = (centres[label] + 0.8 * rng.normal(size=(n, din))).astype(np.float32)
+    order = rng.permutation(n)
+    parts = [np.sort(order[0:n // 3]), np.sort(order[n // 3:2 * n // 3])]      # two training batches
+    held = np.sort(order[2 * n // 3:])                                          # never trained on
+    def batch(idx):
+        return O.as_support_tuple(O.row_normalize(sp.csr_matrix(A[idx][:, idx])))
+    monkeypatch.chdir(tmp_path)
+    cfg = {"dataset": "planted", "spectral": {
+        "architecture": {"n_layers": 4, "hidden_dim1": 64, "hidden_dim2": 64, "hidden_dim3": 32, "output_dim": ncl},
+        "epochs": 150, "lr": 1e-3, "lr_decay": 0.1, "min_lr": 1e-7, "batch_size": 1024, "n_clusters": ncl, "patience": 50}}
+    torch.manual_seed(0)
+    np.random.seed(0)
+    net = SpectralTrainer(cfg, dev).train(
+        ([p for p in parts], [torch.tensor(X[p]) for p in parts], [batch(p) for p in parts], [None] * 2, [None] * 2),
+        ([0], [torch.tensor(X[held])], [batch(held)], [None], [None]))
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("Epoch")]
+    import re
+    first, last = (float(re.findall(r"[-+]?\d+\.\d+", l)[0]) for l in (lines[0], lines[-1]))
+    assert last < 0.6 * first, (first, last)
+    facade = SpectralNet(n_clusters=ncl, config={"should_use_ae": False, "should_use_siamese": False})
+    facade.spec_net = net
+    Y = facade.predict(torch.tensor(X))
+    cen = np.stack([Y[parts[0]][label[parts[0]] == c].mean(0) for c in range(ncl)])     # centres from trained nodes
+    pred = np.argmin(((Y[held][:, None, :] - cen[None]) ** 2).sum(-1), axis=1)
+    acc = float((pred == label[held]).mean())
+    print("planted clusters: loss", first, "->", last, "held-out accuracy", acc)
+    assert acc > 0.9, acc
