@@ -74,3 +74,79 @@ def test_sharded_step_over_rccl_world_of_one():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SPARC_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-c", WORKER], env=env, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0 and "RCCL_STEP_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+WORKER2 = r"""
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["SPARC_ROOT"])
+from sparc_amd import synth
+from sparc_amd.graph import ClusterBatch
+from sparc_amd.parallel import ShardedSpectralTrainer
+
+rank = int(os.environ["RANK"])
+dev = torch.device("cuda:0")                       # both ranks share the one GPU of the test box
+torch.cuda.set_device(dev)
+k, din = 12, 20
+arch = {"n_layers": 6, "hidden_dim1": 64, "hidden_dim2": 64, "hidden_dim3": 32, "output_dim": k}
+graph, bounds = synth.planted_cluster_graph(3000, 12000, 12, dev, seed=3)
+nodes_of, _ = synth.cluster_batches(bounds, 6, seed=0, return_clusters=True)
+
+def run(distributed, same_batches):
+    tr = ShardedSpectralTrainer(arch, din, dev, lr=1e-3, seed=5)
+    assert tr.distributed == distributed
+    for b in range(2):
+        nb = b if same_batches else (2 * b + rank) % len(nodes_of)
+        coords, values, shp, _ = graph.subblock(nodes_of[nb], mode=2, binarize=False, diag_lambda=0.01)
+        tr.add_batch(synth.block_features(nodes_of[nb], bounds, din, 12), ClusterBatch.from_device_coo(shp[0], coords, values).warm(k))
+    rng = np.random.RandomState(0)
+    losses = []
+    for s in range(6):
+        pid, pid_2 = s % 2, (s // 2) % 2
+        losses.append(float(tr.step(pid, pid_2, rng.permutation(tr.batches[pid_2].m)[:k])))
+    return np.array(losses), torch.cat([p.detach().flatten() for p in tr.params])
+
+single = run(False, True)                          # before the process group exists: the single-process trainer
+dist.init_process_group("gloo", rank=rank, world_size=2)
+rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+# both ranks hold the same batches: the mean of two equal gradients is the gradient, so the trajectory is the
+# single-process one (the all-reduce, the bucket views and the averaging all take part)
+same = run(True, True)
+assert rel(same[0], single[0]) < 1e-6, (same[0], single[0])
+assert rel(same[1].cpu().numpy(), single[1].cpu().numpy()) < 1e-6
+# different batches per rank: the replicas stay identical bit for bit, and the step still descends
+diff = run(True, False)
+both = [torch.empty_like(diff[1]) for _ in range(2)]
+dist.all_gather(both, diff[1])
+assert torch.equal(both[0], both[1])
+assert np.isfinite(diff[0]).all()
+dist.barrier()
+dist.destroy_process_group()
+print("GLOO2_STEP_OK", rank)
+"""
+
+
+def test_sharded_step_two_ranks_on_one_gpu():
+    """Two ranks (gloo) drive the real kernels on the one GPU: with equal batches on both ranks the averaged step is the
+    single-process step; with different batches the replicas stay bitwise identical."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SPARC_ROOT=ROOT, RANK=str(r), WORLD_SIZE="2",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER2], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=240))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for r, (p, (o, e)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"GLOO2_STEP_OK {r}" in o, o[-2000:] + e[-4000:]
