@@ -8,9 +8,12 @@
 //   hipcc --offload-arch=gfx950 -O3 -o pblocks_proto pblocks_proto.hip && ./pblocks_proto [mode]
 // mode bits (ablation): 1 = no products, 2 = no staging, 4 = no epilogue stores; 32 = also time every launch behind
 // 300 us of matrix work (the clocks inside a training step).  Further arguments: clusters, rows per cluster, fill.
-// Measured (50 clusters of 490 rows, 32.8 entries per row, 96 operand columns): 13.5 us per pass in the best geometry
-// (8 waves x 2 row tiles), of which 6.3 us are the 461 k matrix instructions (two thirds of their peak rate: 600 units
-// over 256 CUs), 0.7 us the staging that does not hide behind them and 6.7 us launch, barriers and the epilogue.
+// Measured (50 clusters of 490 rows, 32.8 entries per row, 96 operand columns), best geometry (8 waves x 2 row tiles):
+// 13.2 us per pass with the dense pattern (461 k matrix instructions), 12.0 us with the pattern in 2:4 form on
+// v_smfmac_f32_16x16x64_bf16 (half as many; 0.43 % of the entries do not fit two-of-four and would join the gathered
+// remainder).  Without the products 7.4 us (launch, staging that does not hide, barriers, epilogue).  Halving the
+// matrix instructions saves 1.2 us only: every wave re-reads the whole B operand of its unit from LDS (6 KB per 64
+// operand rows), which bounds the product phase next; wider row tiles per wave would cut that.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -22,6 +25,7 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x16 __attribute__((ext_vector_type(16)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -35,6 +39,8 @@ struct Args {
     float* out;
     const float* rowpat;  // [m][4] = {r, delta, delta / r, 1 / r}
     const unsigned* bits; // per cluster: [row tile][k group of 128][lane]
+    const unsigned* svals; // 2:4 form: per cluster [row tile][k group of 256][lane]: the stored elements (bit pairs as above)
+    const unsigned* sidx;  //           per cluster [row tile][k group of 128][lane]: their 2-bit positions, 16 bits per step of 64
     const int* desc;      // per unit: {w0, P, column tile, first row tile of the part, bitmap offset (dwords), KP}
     int64_t plane;        // floats per slab
     int mode;
@@ -50,7 +56,9 @@ __device__ __forceinline__ unsigned hi_pair(const float a, const float b) {   //
     return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
 }
 
-template <int WAVES, int RT>
+// SP: the pattern in 2:4 form on v_smfmac_f32_16x16x64_bf16 (lane (row, g) stores two of every four consecutive k of
+// its 16; measured operand layout: tools/kbench/smfmac_probe.hip), half as many matrix instructions.
+template <int WAVES, int RT, bool SP = false>
 __global__ __launch_bounds__(WAVES * 64) void pblocks(const Args a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -64,13 +72,19 @@ __global__ __launch_bounds__(WAVES * 64) void pblocks(const Args a) {
 
     // the pattern bits of this wave's row tiles
     unsigned dw[RT][4];
+    unsigned sv[RT][2], si[RT][4];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+    for (int rt = 0; rt < RT; ++rt) {
+        const int tile = tile0 + wave * RT + rt;
+        const bool live = tile * 16 < P;
 #pragma unroll
         for (int G = 0; G < 4; ++G) {
-            const int tile = tile0 + wave * RT + rt;
-            dw[rt][G] = (G < NG && tile * 16 < P) ? a.bits[boff + (tile * NG + G) * 64 + lane] : 0u;
+            dw[rt][G] = (!SP && G < NG && live) ? a.bits[boff + (tile * NG + G) * 64 + lane] : 0u;
+            si[rt][G] = (SP && G < NG && live) ? a.sidx[boff + (tile * NG + G) * 64 + lane] : 0u;
         }
+#pragma unroll
+        for (int H = 0; H < 2; ++H) sv[rt][H] = (SP && 2 * H < NG && live) ? a.svals[boff / 2 + (tile * (NG / 2) + H) * 64 + lane] : 0u;
+    }
 
     // operand rows travel in chunks of 128 rows: chunk G + 1 is requested before the products of chunk G and
     // split into its three bf16 planes behind them
@@ -119,7 +133,38 @@ __global__ __launch_bounds__(WAVES * 64) void pblocks(const Args a) {
         if (G >= NG) break;
         if (G + 1 < NG) request(G + 1);
         __syncthreads();   // chunk G is in LDS
-        if (!(a.mode & 1)) {
+        if (!(a.mode & 1) && SP) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {   // two steps of 64 operand rows per chunk
+                const int koff = (G * 4 + 2 * s2) * 1024;
+                bf16x16 b[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    struct { s16x4 x, y, z, w; } bb;
+                    bb.x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)(a0 + koff + pl * plane_bytes));
+                    bb.y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)(a1 + koff + pl * plane_bytes));
+                    bb.z = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)(a0 + koff + 1024 + pl * plane_bytes));
+                    bb.w = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)(a1 + koff + 1024 + pl * plane_bytes));
+                    b[pl] = __builtin_bit_cast(bf16x16, bb);
+                }
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const unsigned w = sv[rt][G >> 1];
+                    const int s4 = (G & 1) * 2 + s2;   // step inside the word of stored elements (256 operand rows)
+                    u32x4 au;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 4 * s4 + r;
+                        au[r] = (i < 15 ? (w << (14 - i)) : (w >> 1)) & 0x40004000u;
+                    }
+                    const bf16x8 av = __builtin_bit_cast(bf16x8, au);
+                    const int ix = static_cast<int>(s2 ? si[rt][G] >> 16 : si[rt][G]);
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) acc[rt] = __builtin_amdgcn_smfmac_f32_16x16x64_bf16(av, b[pl], acc[rt], ix, 0, 0);
+                }
+            }
+        }
+        if (!(a.mode & 1) && !SP) {
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 const int koff = (G * 4 + s4) * 1024;
@@ -212,15 +257,15 @@ __global__ __launch_bounds__(256) void heater(float* out, int iters) {
 }
 static bool g_heat = false;
 
-template <int WAVES, int RT>
+template <int WAVES, int RT, bool SP = false>
 static void run(const char* name, const Args& a, int units, int lds_bytes, hipStream_t st, int reps, double alg_bytes) {
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pblocks<WAVES, RT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pblocks<WAVES, RT, SP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 50; ++i) hipLaunchKernelGGL((pblocks<WAVES, RT>), dim3(units), dim3(WAVES * 64), lds_bytes, st, a);
+    for (int i = 0; i < 50; ++i) hipLaunchKernelGGL((pblocks<WAVES, RT, SP>), dim3(units), dim3(WAVES * 64), lds_bytes, st, a);
     CK(hipStreamSynchronize(st));
     CK(hipEventRecord(e0, st));
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((pblocks<WAVES, RT>), dim3(units), dim3(WAVES * 64), lds_bytes, st, a);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((pblocks<WAVES, RT, SP>), dim3(units), dim3(WAVES * 64), lds_bytes, st, a);
     CK(hipEventRecord(e1, st));
     CK(hipStreamSynchronize(st));
     float ms = 0.f;
@@ -231,7 +276,7 @@ static void run(const char* name, const Args& a, int units, int lds_bytes, hipSt
         for (int i = 0; i < reps; ++i) {
             hipLaunchKernelGGL(heater, dim3(1024), dim3(256), 0, st, a.out, 2000);
             CK(hipEventRecord(ev[2 * i], st));
-            hipLaunchKernelGGL((pblocks<WAVES, RT>), dim3(units), dim3(WAVES * 64), lds_bytes, st, a);
+            hipLaunchKernelGGL((pblocks<WAVES, RT, SP>), dim3(units), dim3(WAVES * 64), lds_bytes, st, a);
             CK(hipEventRecord(ev[2 * i + 1], st));
         }
         CK(hipStreamSynchronize(st));
@@ -249,7 +294,7 @@ int main(int argc, char** argv) {
     g_heat = argc > 1 && (atoi(argv[1]) & 32);
     const int NC = argc > 2 ? atoi(argv[2]) : 50, P = argc > 3 ? atoi(argv[3]) : 490, NSLAB = 3;
     const double fill = argc > 4 ? atof(argv[4]) : 0.065;
-    const int KP = (P + 127) / 128 * 128, NG = KP / 128, NT = (P + 15) / 16;
+    const int KP = (P + 255) / 256 * 256, NG = KP / 128, NT = (P + 15) / 16;
     const int64_t m = static_cast<int64_t>(NC) * P, plane = m * RW;
     std::mt19937 rng(1);
     std::uniform_real_distribution<float> uf(-1.f, 1.f);
@@ -294,7 +339,43 @@ int main(int argc, char** argv) {
                     bits[static_cast<size_t>(c) * bits_per_cluster + (t * NG + G) * 64 + l] = w;
                 }
     }
-    float *dX, *dX0, *dout, *drp; unsigned* dbits; int* ddesc;
+    // the same pattern in 2:4 form: of every four consecutive k (inside a lane's 16) two are stored with their
+    // positions; further entries of such a group would go to the gathered remainder and are dropped here (counted)
+    std::vector<unsigned> svals(bits.size() / 2, 0u), sidx(bits.size(), 0u);
+    std::vector<uint8_t> kept(pat);
+    size_t dropped = 0;
+    for (int c = 0; c < NC; ++c) {
+        uint8_t* A = kept.data() + static_cast<size_t>(c) * P * P;
+        for (int t = 0; t < NT; ++t)
+            for (int st = 0; st < KP / 64; ++st)
+                for (int l = 0; l < 64; ++l) {
+                    const int row = 16 * t + (l & 15), ga = l >> 4;
+                    if (row >= P) continue;
+                    unsigned vbits = 0, ix = 0;
+                    for (int j = 0; j < 4; ++j) {
+                        int pos[2] = {0, 3}, n = 0;
+                        for (int q = 0; q < 4; ++q) {
+                            const int k = 64 * st + 16 * ga + 4 * j + q;
+                            if (k < P && A[row * P + k]) {
+                                if (n < 2) pos[n++] = q;
+                                else { A[row * P + k] = 0; ++dropped; }
+                            }
+                        }
+                        if (n == 1 && pos[0] == 3) pos[1] = 0;
+                        const int s4 = st % 4;
+                        if (n >= 1) vbits |= 1u << (4 * s4 + j);
+                        if (n >= 2) vbits |= 1u << (4 * s4 + j + 16);
+                        ix |= static_cast<unsigned>(pos[0]) << (4 * j) | static_cast<unsigned>(pos[1]) << (4 * j + 2);
+                    }
+                    svals[static_cast<size_t>(c) * bits_per_cluster / 2 + (t * (NG / 2) + st / 4) * 64 + l] |= vbits;
+                    sidx[static_cast<size_t>(c) * bits_per_cluster + (t * NG + st / 2) * 64 + l] |= ix << (16 * (st % 2));
+                }
+    }
+    printf("2:4 form: %zu of %zu entries do not fit (%.2f %%)\n", dropped, nnz, 100.0 * dropped / nnz);
+    float *dX, *dX0, *dout, *drp; unsigned* dbits; int* ddesc; unsigned *dsv, *dsi;
+    CK(hipMalloc(&dsv, svals.size() * 4)); CK(hipMalloc(&dsi, sidx.size() * 4));
+    CK(hipMemcpy(dsv, svals.data(), svals.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dsi, sidx.data(), sidx.size() * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&dX, X.size() * 4)); CK(hipMalloc(&dX0, X.size() * 4)); CK(hipMalloc(&dout, X.size() * 4));
     CK(hipMalloc(&drp, rowpat.size() * 4)); CK(hipMalloc(&dbits, bits.size() * 4));
     CK(hipMemcpy(dX, X.data(), X.size() * 4, hipMemcpyHostToDevice));
@@ -324,7 +405,7 @@ int main(int argc, char** argv) {
                 for (int e = 0; e < 8; ++e) desc[(j * 8 + x) * 8 + e] = per[x][j * 8 + e];
         return static_cast<int>(desc.size() / 8);
     };
-    Args a{dX, dX0, dout, drp, dbits, nullptr, plane, mode};
+    Args a{dX, dX0, dout, drp, dbits, dsv, dsi, nullptr, plane, mode};
     std::vector<int> desc;
     const int lds_bytes = 3 * KP * PLANE_ROW;
     auto with_desc = [&](int rows_per_unit) {
@@ -337,26 +418,21 @@ int main(int argc, char** argv) {
     };
     ddesc = nullptr;
     int units = with_desc(128);
-    // correctness of the first configuration against a double sum
-    CK(hipMemset(dout, 0, X.size() * 4));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pblocks<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-    hipLaunchKernelGGL((pblocks<4, 2>), dim3(units), dim3(256), lds_bytes, st, a);
-    CK(hipStreamSynchronize(st));
+    // correctness of the first configuration of both forms against a double sum
     std::vector<float> out(X.size());
-    CK(hipMemcpy(out.data(), dout, X.size() * 4, hipMemcpyDeviceToHost));
-    if (mode == 0) {
+    auto check = [&](const char* what, const std::vector<uint8_t>& pt) {
         double worst = 0.0, worst32 = 0.0;
         for (int c : {0, NC / 2, NC - 1}) {
-            const uint8_t* A = pat.data() + static_cast<size_t>(c) * P * P;
+            const uint8_t* A = pt.data() + static_cast<size_t>(c) * P * P;
             for (int i = 0; i < P; ++i) {
                 const int64_t row = static_cast<int64_t>(c) * P + i;
                 const float* rp = &rowpat[row * 4];
-                for (int s = 0; s < NSLAB; ++s)
+                for (int sl = 0; sl < NSLAB; ++sl)
                     for (int cc = 0; cc < RW; ++cc) {
                         double sum = 0.0; float sum32 = 0.f;
                         for (int k = 0; k < P; ++k)
-                            if (A[i * P + k]) { sum += X[s * plane + (static_cast<int64_t>(c) * P + k) * RW + cc]; sum32 += X[s * plane + (static_cast<int64_t>(c) * P + k) * RW + cc]; }
-                        const int64_t at = s * plane + row * RW + cc;
+                            if (A[i * P + k]) { sum += X[sl * plane + (static_cast<int64_t>(c) * P + k) * RW + cc]; sum32 += X[sl * plane + (static_cast<int64_t>(c) * P + k) * RW + cc]; }
+                        const int64_t at = sl * plane + row * RW + cc;
                         auto fin = [&](double sm) {
                             return cc >= 16 ? (sm + double(rp[2]) * X[at] + double(X0[at]) * rp[3]) * rp[0]
                                             : rp[0] * sm + double(rp[1]) * X[at] + X0[at];
@@ -367,11 +443,28 @@ int main(int argc, char** argv) {
                     }
             }
         }
-        printf("largest error against a double sum: %.3g (a sequential fp32 sum: %.3g)\n", worst, worst32);
+        printf("%s: largest error against a double sum: %.3g (a sequential fp32 sum: %.3g)\n", what, worst, worst32);
+    };
+    if (mode == 0) {
+        CK(hipMemset(dout, 0, X.size() * 4));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pblocks<4, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        hipLaunchKernelGGL((pblocks<4, 2, false>), dim3(units), dim3(256), lds_bytes, st, a);
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(out.data(), dout, X.size() * 4, hipMemcpyDeviceToHost));
+        check("dense pattern", pat);
+        CK(hipMemset(dout, 0, X.size() * 4));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pblocks<4, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        hipLaunchKernelGGL((pblocks<4, 2, true>), dim3(units), dim3(256), lds_bytes, st, a);
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(out.data(), dout, X.size() * 4, hipMemcpyDeviceToHost));
+        check("2:4 pattern  ", kept);
     }
     const int reps = 200;
     run<4, 2>("4 waves x 2 row tiles (128 rows per unit)", a, units, lds_bytes, st, reps, alg);
+    run<4, 2, true>("2:4 form, 4 waves x 2 row tiles (128 rows per unit)", a, units, lds_bytes, st, reps, alg);
     units = with_desc(256);
+    run<8, 2, true>("2:4 form, 8 waves x 2 row tiles (256 rows per unit)", a, units, lds_bytes, st, reps, alg);
+    run<4, 4, true>("2:4 form, 4 waves x 4 row tiles (256 rows per unit)", a, units, lds_bytes, st, reps, alg);
     run<4, 4>("4 waves x 4 row tiles (256 rows per unit)", a, units, lds_bytes, st, reps, alg);
     run<8, 2>("8 waves x 2 row tiles (256 rows per unit)", a, units, lds_bytes, st, reps, alg);
     units = with_desc(512);
