@@ -13,7 +13,9 @@
 // v_smfmac_f32_16x16x64_bf16 (half as many; 0.43 % of the entries do not fit two-of-four and would join the gathered
 // remainder).  Without the products 7.4 us (launch, staging that does not hide, barriers, epilogue).  Halving the
 // matrix instructions saves 1.2 us only: every wave re-reads the whole B operand of its unit from LDS (6 KB per 64
-// operand rows), which bounds the product phase next; wider row tiles per wave would cut that.
+// operand rows).  Second geometry (pblocks32: 32 x 32 tiles on v_smfmac_f32_32x32x32_bf16, chunks through a ring of
+// two LDS buffers): 13.0 us at best; its products take as long (4.6 us against 3.9 us) and its part without the products
+// is longer (8.6 us: fewer units to stage with, the own row from global memory).  So this family ends near 11.7 us.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -242,6 +244,169 @@ __global__ __launch_bounds__(WAVES * 64) void pblocks(const Args a) {
     }
 }
 
+// Second geometry: 32-row x 32-column tiles on v_smfmac_f32_32x32x32_bf16 (the pattern in 2:4 form), a whole slab row
+// (16 columns of each half) per unit, operand chunks of 128 rows streamed through a ring of two LDS buffers (48 KB), so
+// that a wave's B operand serves 32 rows x 32 columns: half the LDS reads per product of the 16 x 16 geometry.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+struct Args32 {
+    const float* X; const float* X0; float* out; const float* rowpat;
+    const unsigned* svals;   // per cluster [32-row tile][k group of 128][lane]
+    const unsigned* sidx;    // per cluster [32-row tile][k group of 64][lane]
+    const int* desc;         // per unit: {w0, P, slab, first 32-row tile, offset of the cluster's svals (dwords), KP}
+    int64_t plane; int mode;
+};
+
+template <int WAVES, int RT>
+__global__ __launch_bounds__(WAVES * 64) void pblocks32(const Args32 a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int NT = WAVES * 64, CHUNK = 24576, PLANE = 8192;   // 128 rows x 64 B per plane, three planes per chunk
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int* d = a.desc + blockIdx.x * 8;
+    const int w0 = d[0], P = d[1], slab = d[2], tile0 = d[3], voff = d[4], KP = d[5];
+    if (P == 0) return;
+    const int NG = KP >> 7;
+    const float* Xs = a.X + slab * a.plane + static_cast<int64_t>(w0) * RW;
+    unsigned sv[RT][4], si[RT][8];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int tile = tile0 + wave * RT + rt;
+        const bool live = tile * 32 < P;
+#pragma unroll
+        for (int G = 0; G < 4; ++G) sv[rt][G] = (G < NG && live) ? a.svals[voff + (tile * NG + G) * 64 + lane] : 0u;
+#pragma unroll
+        for (int H = 0; H < 8; ++H) si[rt][H] = (H < 2 * NG && live) ? a.sidx[2 * voff + (tile * 2 * NG + H) * 64 + lane] : 0u;
+    }
+    constexpr int CL = (1024 + NT - 1) / NT;   // float4 loads per thread and chunk (128 rows x 8)
+    float4 v[CL];
+    auto request = [&](const int G) {
+#pragma unroll
+        for (int u = 0; u < CL; ++u) {
+            const int idx = u * NT + tid;
+            const int k = G * 128 + (idx >> 3), qd = idx & 7;
+            v[u] = (idx < 1024 && k < P && !(a.mode & 2)) ? *reinterpret_cast<const float4*>(Xs + k * RW + qd * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto split_store = [&](const int G) {
+        char* buf = lds + (G & 1) * CHUNK;
+#pragma unroll
+        for (int u = 0; u < CL; ++u) {
+            const int idx = u * NT + tid;
+            if (idx < 1024) {
+                const float x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                float r1[4], r2[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    r1[i] = x[i] - __uint_as_float(__float_as_uint(x[i]) & 0xffff0000u);
+                    r2[i] = r1[i] - __uint_as_float(__float_as_uint(r1[i]) & 0xffff0000u);
+                }
+                char* p = buf + idx * 8;   // row (idx >> 3) x 64 B + quad (idx & 7) x 8 B
+                *reinterpret_cast<uint2*>(p) = make_uint2(hi_pair(x[0], x[1]), hi_pair(x[2], x[3]));
+                *reinterpret_cast<uint2*>(p + PLANE) = make_uint2(hi_pair(r1[0], r1[1]), hi_pair(r1[2], r1[3]));
+                *reinterpret_cast<uint2*>(p + 2 * PLANE) = make_uint2(hi_pair(r2[0], r2[1]), hi_pair(r2[2], r2[3]));
+            }
+        }
+    };
+    request(0);
+    split_store(0);
+    f32x16 acc[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
+    // transposed reads: group g16 of 16 lanes takes rows 8 (g16 >> 1) + 4 t + q, columns 16 (g16 & 1) + 4 p ...
+    const int g16 = lane >> 4, q = (lane & 15) >> 2, p4 = lane & 3;
+    const int lbase = static_cast<int>(reinterpret_cast<uintptr_t>(lds)) + 64 * (8 * (g16 >> 1) + q) + 32 * (g16 & 1) + 8 * p4;
+#pragma unroll
+    for (int G = 0; G < 4; ++G) {
+        if (G >= NG) break;
+        if (G + 1 < NG) request(G + 1);
+        __syncthreads();   // chunk G is in LDS, and nobody reads the buffer of chunk G - 1 any more
+        if (!(a.mode & 1)) {
+            const int cb = lbase + (G & 1) * CHUNK;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {   // four steps of 32 operand rows
+                bf16x16 b[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const int at = cb + s4 * 2048 + pl * PLANE;
+                    struct { s16x4 x, y, z, w; } bb;
+                    bb.x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)(at));
+                    bb.y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)(at + 256));
+                    bb.z = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)(at + 1024));
+                    bb.w = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)(at + 1280));
+                    b[pl] = __builtin_bit_cast(bf16x16, bb);
+                }
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const unsigned w = sv[rt][G];
+                    u32x4 au;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 4 * s4 + r;
+                        au[r] = (i < 15 ? (w << (14 - i)) : (w >> 1)) & 0x40004000u;
+                    }
+                    const bf16x8 av = __builtin_bit_cast(bf16x8, au);
+                    const unsigned iw = si[rt][2 * G + (s4 >> 1)];
+                    const int ix = static_cast<int>((s4 & 1) ? iw >> 16 : iw);
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) acc[rt] = __builtin_amdgcn_smfmac_f32_32x32x32_bf16(av, b[pl], acc[rt], ix, 0, 0);
+                }
+            }
+        }
+        if (G + 1 < NG) split_store(G + 1);
+    }
+    __syncthreads();   // the ring is free: it becomes the transposition scratch (4 KB per wave)
+    float* scratch = reinterpret_cast<float*>(lds) + wave * 1024;
+    const int lk = lane >> 5, li = lane & 31;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int tile = tile0 + wave * RT + rt;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) scratch[(8 * (r >> 2) + 4 * lk + (r & 3)) * 32 + li] = acc[rt][r];
+        // (a wave reads back only what it wrote itself: no barrier)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int rr = (lane >> 3) + 8 * t, qd = lane & 7;
+            const int rl = tile * 32 + rr;
+            const float4 tv4 = *reinterpret_cast<const float4*>(scratch + rr * 32 + qd * 4);
+            if (rl < P) {
+                const int64_t row = w0 + rl;
+                const float4 rp = *reinterpret_cast<const float4*>(a.rowpat + row * 4);
+                const int64_t at = slab * a.plane + row * RW + qd * 4;
+                const float4 x0 = *reinterpret_cast<const float4*>(a.X0 + at);
+                const float4 ow = *reinterpret_cast<const float4*>(a.X + at);
+                const bool right = qd >= 4;
+                const float tv[4] = {tv4.x, tv4.y, tv4.z, tv4.w}, ov[4] = {ow.x, ow.y, ow.z, ow.w}, xv[4] = {x0.x, x0.y, x0.z, x0.w};
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float vv = 0.5f * tv[e];
+                    o[e] = right ? (fmaf(rp.z, ov[e], vv) + xv[e] * rp.w) * rp.x : fmaf(rp.x, vv, rp.y * ov[e]) + xv[e];
+                }
+                if (!(a.mode & 4)) *reinterpret_cast<float4*>(a.out + at) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+}
+
+template <int WAVES, int RT>
+static void run32(const char* name, const Args32& a, int units, hipStream_t st, int reps, double alg_bytes) {
+    const int lds_bytes = 49152;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pblocks32<WAVES, RT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 50; ++i) hipLaunchKernelGGL((pblocks32<WAVES, RT>), dim3(units), dim3(WAVES * 64), lds_bytes, st, a);
+    CK(hipStreamSynchronize(st));
+    CK(hipEventRecord(e0, st));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((pblocks32<WAVES, RT>), dim3(units), dim3(WAVES * 64), lds_bytes, st, a);
+    CK(hipEventRecord(e1, st));
+    CK(hipStreamSynchronize(st));
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%s: %d units x %d threads: %.2f us per launch (%.2f TB/s of %.1f MB)\n", name, units, WAVES * 64, ms * 1e3 / reps,
+           alg_bytes / (ms * 1e-3 / reps) / 1e12, alg_bytes / 1e6);
+}
+
 // keeps the matrix cores busy between two timed launches, as the GEMMs of a training step do (clocks of an idle chip
 // are lower than those the kernel sees inside a step)
 __global__ __launch_bounds__(256) void heater(float* out, int iters) {
@@ -458,6 +623,78 @@ int main(int argc, char** argv) {
         CK(hipStreamSynchronize(st));
         CK(hipMemcpy(out.data(), dout, X.size() * 4, hipMemcpyDeviceToHost));
         check("2:4 pattern  ", kept);
+    }
+    // 32-row tiles: the same 2:4 pattern for v_smfmac_f32_32x32x32_bf16 (lane = row % 32 + 32 ga, 16 k per step of 32)
+    const int NT32 = (P + 31) / 32, per32 = NT32 * NG * 64;
+    std::vector<unsigned> sv32(static_cast<size_t>(NC) * per32, 0u), si32(static_cast<size_t>(NC) * per32 * 2, 0u);
+    for (int c = 0; c < NC; ++c) {
+        const uint8_t* A = kept.data() + static_cast<size_t>(c) * P * P;
+        for (int t = 0; t < NT32; ++t)
+            for (int stp = 0; stp < KP / 32; ++stp)
+                for (int l = 0; l < 64; ++l) {
+                    const int row = 32 * t + (l & 31), ga = l >> 5;
+                    if (row >= P) continue;
+                    unsigned vbits = 0, ix = 0;
+                    for (int j = 0; j < 4; ++j) {
+                        int pos[2] = {0, 3}, n = 0;
+                        for (int qq = 0; qq < 4; ++qq) {
+                            const int k = 32 * stp + 16 * ga + 4 * j + qq;
+                            if (k < P && A[row * P + k] && n < 2) pos[n++] = qq;
+                        }
+                        if (n == 1 && pos[0] == 3) pos[1] = 0;
+                        const int s4 = stp % 4;
+                        if (n >= 1) vbits |= 1u << (4 * s4 + j);
+                        if (n >= 2) vbits |= 1u << (4 * s4 + j + 16);
+                        ix |= static_cast<unsigned>(pos[0]) << (4 * j) | static_cast<unsigned>(pos[1]) << (4 * j + 2);
+                    }
+                    sv32[static_cast<size_t>(c) * per32 + (t * NG + stp / 4) * 64 + l] |= vbits;
+                    si32[static_cast<size_t>(c) * per32 * 2 + (t * 2 * NG + stp / 2) * 64 + l] |= ix << (16 * (stp % 2));
+                }
+    }
+    unsigned *dsv32, *dsi32; int* ddesc32 = nullptr;
+    CK(hipMalloc(&dsv32, sv32.size() * 4)); CK(hipMalloc(&dsi32, si32.size() * 4));
+    CK(hipMemcpy(dsv32, sv32.data(), sv32.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dsi32, si32.data(), si32.size() * 4, hipMemcpyHostToDevice));
+    Args32 a32{dX, dX0, dout, drp, dsv32, dsi32, nullptr, plane, mode};
+    auto with_desc32 = [&](int rows_per_unit) {
+        const int tiles_per_unit = rows_per_unit / 32;
+        std::vector<std::vector<int>> per(8);
+        for (int c = 0; c < NC; ++c)
+            for (int sl = 0; sl < NSLAB; ++sl)
+                for (int t0 = 0; t0 < NT32; t0 += tiles_per_unit) {
+                    const int dsc[8] = {c * P, P, sl, t0, c * per32, KP, 0, 0};
+                    per[c % 8].insert(per[c % 8].end(), dsc, dsc + 8);
+                }
+        size_t longest = 0;
+        for (auto& v : per) longest = std::max(longest, v.size() / 8);
+        std::vector<int> dd(longest * 8 * 8, 0);
+        for (int x = 0; x < 8; ++x)
+            for (size_t j = 0; j < per[x].size() / 8; ++j)
+                for (int e = 0; e < 8; ++e) dd[(j * 8 + x) * 8 + e] = per[x][j * 8 + e];
+        if (ddesc32) CK(hipFree(ddesc32));
+        CK(hipMalloc(&ddesc32, dd.size() * 4));
+        CK(hipMemcpy(ddesc32, dd.data(), dd.size() * 4, hipMemcpyHostToDevice));
+        a32.desc = ddesc32;
+        return static_cast<int>(dd.size() / 8);
+    };
+    if (KP <= 512) {
+        int u32 = with_desc32(256);
+        if (mode == 0) {
+            CK(hipMemset(dout, 0, X.size() * 4));
+            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pblocks32<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 49152));
+            hipLaunchKernelGGL((pblocks32<4, 2>), dim3(u32), dim3(256), 49152, st, a32);
+            CK(hipStreamSynchronize(st));
+            CK(hipMemcpy(out.data(), dout, X.size() * 4, hipMemcpyDeviceToHost));
+            check("2:4 pattern, 32-row tiles", kept);
+        }
+        run32<4, 2>("32 x 32 tiles, 4 waves x 2 row tiles (256 rows per unit)", a32, u32, st, 200, alg);
+        run32<8, 1>("32 x 32 tiles, 8 waves x 1 row tile (256 rows per unit)", a32, u32, st, 200, alg);
+        u32 = with_desc32(128);
+        run32<4, 1>("32 x 32 tiles, 4 waves x 1 row tile (128 rows per unit)", a32, u32, st, 200, alg);
+        run32<2, 2>("32 x 32 tiles, 2 waves x 2 row tiles (128 rows per unit)", a32, u32, st, 200, alg);
+        u32 = with_desc32(512);
+        run32<8, 2>("32 x 32 tiles, 8 waves x 2 row tiles (512 rows per unit)", a32, u32, st, 200, alg);
+        run32<4, 4>("32 x 32 tiles, 4 waves x 4 row tiles (512 rows per unit)", a32, u32, st, 200, alg);
     }
     const int reps = 200;
     run<4, 2>("4 waves x 2 row tiles (128 rows per unit)", a, units, lds_bytes, st, reps, alg);

@@ -24,6 +24,20 @@ __global__ void probe(const unsigned short* A, const unsigned short* B, const in
     for (int i = 0; i < 4; ++i) out[l * 4 + i] = c[i];
 }
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__global__ void probe32(const unsigned short* A, const unsigned short* B, const int* idx, float* out) {
+    const int l = threadIdx.x;
+    bf16x8 a; bf16x16 b;
+    unsigned short ar[8], br[16];
+    for (int i = 0; i < 8; ++i) ar[i] = A[l * 8 + i];
+    for (int i = 0; i < 16; ++i) br[i] = B[l * 16 + i];
+    __builtin_memcpy(&a, ar, 16); __builtin_memcpy(&b, br, 32);
+    f32x16 c;
+    for (int i = 0; i < 16; ++i) c[i] = 0.f;
+    c = __builtin_amdgcn_smfmac_f32_32x32x32_bf16(a, b, c, idx[l], 0, 0);
+    for (int i = 0; i < 16; ++i) out[l * 16 + i] = c[i];
+}
+
 static unsigned short bf16_of(float f) { unsigned u; memcpy(&u, &f, 4); return static_cast<unsigned short>(u >> 16); }
 
 int main() {
@@ -66,6 +80,45 @@ int main() {
                         }
                 int nz = 0;
                 for (float x : O) nz += x != 0.f;
+                printf("  (%d outputs set)\n", nz);
+            }
+    // v_smfmac_f32_32x32x32_bf16: lane groups of 32
+    printf("---- 32x32x32\n");
+    float* dO32; CK(hipMalloc(&dO32, 64 * 16 * 4));
+    std::vector<float> P(1024), P2(1024);
+    for (int g = 0; g < 2; ++g)
+        for (int s = 0; s < 8; ++s)
+            for (int v = 0; v < 4; v += 3) {
+                std::fill(A.begin(), A.end(), 0);
+                for (int l = 32 * g; l < 32 * g + 32; ++l) A[l * 8 + s] = bf16_of(1.f);
+                for (int l = 0; l < 64; ++l) {
+                    int w = 0;
+                    for (int t = 0; t < 8; ++t) w |= ((t == s ? v : ((t & 1) ? 3 : 0))) << (2 * t);
+                    I[l] = w;
+                }
+                CK(hipMemcpy(dA, A.data(), A.size() * 2, hipMemcpyHostToDevice));
+                CK(hipMemcpy(dI, I.data(), I.size() * 4, hipMemcpyHostToDevice));
+                for (int pass = 0; pass < 2; ++pass) {
+                    for (int lb = 0; lb < 64; ++lb)
+                        for (int e = 0; e < 16; ++e) {
+                            const int code = lb * 16 + e;
+                            B[lb * 16 + e] = bf16_of(pass == 0 ? float(code % 128 + 1) : float(code / 128 + 1));
+                        }
+                    CK(hipMemcpy(dB, B.data(), B.size() * 2, hipMemcpyHostToDevice));
+                    hipLaunchKernelGGL(probe32, dim3(1), dim3(64), 0, 0, dA, dB, dI, dO32);
+                    CK(hipMemcpy(pass == 0 ? P.data() : P2.data(), dO32, 4096, hipMemcpyDeviceToHost));
+                }
+                printf("A lanes %2d..%2d slot %d pos %d:", 32 * g, 32 * g + 31, s, v);
+                int shown = 0;
+                for (int l = 0; l < 64 && shown < 2; l += 33)
+                    for (int r = 0; r < 16 && shown < 2; r += 5)
+                        if (P[l * 16 + r] != 0.f) {
+                            const int code = (int(P[l * 16 + r]) - 1) + 128 * (int(P2[l * 16 + r]) - 1);
+                            printf("  out[lane %d reg %d] <- B[lane %d elem %d]", l, r, code / 16, code % 16);
+                            ++shown;
+                        }
+                int nz = 0;
+                for (float x : P) nz += x != 0.f;
                 printf("  (%d outputs set)\n", nz);
             }
     return 0;
