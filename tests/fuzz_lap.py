@@ -2,7 +2,7 @@
 """Randomised cross-check of the Laplacian pass on the GPU: random cluster batches (cluster counts and sizes, densities,
 support flavours, k, training / forward-only) through every kernel path the batch offers (row kernel, windowed kernel
 with value streams and in row-factor form, dense blocks), all against the row kernel, and the small ones against the
-CPU oracle as well.  Not a test (minutes of GPU time): python tools/fuzz_lap.py [seeds] [first seed]"""
+CPU oracle as well.  Not a test (minutes of GPU time): python tests/fuzz_lap.py [seeds] [first seed]"""
 import os
 import sys
 import numpy as np

@@ -534,7 +534,7 @@ def test_trainer_end_to_end_matches_reference(dev, golden, tmp_path, monkeypatch
         return [float(x) for x in re.findall(r"[-+]?\d+\.\d+", line)]
     for a, b in zip(our_lines, ref_lines):
         na, nb = nums(a), nums(b)
-        # observed on an MI355X: 3e-7 (tools/tol_probe.py); the printed losses carry 7 decimals
+        # observed on an MI355X: 3e-7 (tests/tol_probe.py); the printed losses carry 7 decimals
         assert abs(na[0] - nb[0]) / nb[0] < 1e-5 and abs(na[1] - nb[1]) / nb[1] < 1e-5, (a, b)
     # initialisation used the same torch RNG stream as the reference
     for name, p in net.state_dict().items():
