@@ -8,7 +8,16 @@
 
 #include "common.h"
 
+// The compiler contracts a * b + c into a fused multiply-add by default, also across HIP's __dmul_rn / __dadd_rn
+// (plain operators compiled in a header, where contraction is allowed): one rounding where the reference has two.
+// The operations of this file are therefore written here, with contraction off.
+#pragma clang fp contract(off)
+
 namespace {
+
+__device__ __forceinline__ double add_rn(const double a, const double b) { return a + b; }
+__device__ __forceinline__ double mul_rn(const double a, const double b) { return a * b; }
+__device__ __forceinline__ double div_rn(const double a, const double b) { return a / b; }
 
 constexpr int MODE_RAW = 0, MODE_ROWNORM = 1, MODE_ENHANCE = 2;
 
@@ -37,12 +46,12 @@ __global__ void count_rows(int64_t m, const int64_t* __restrict__ indptr, const 
         const int32_t gj = indices[p];
         if (inv[gj] < 0) continue;
         ++c;
-        s = __dadd_rn(s, binarize ? 1.0 : data[p]);
+        s = add_rn(s, binarize ? 1.0 : data[p]);
         if (gj == gi) has_diag = true;
     }
     if (mode == MODE_ENHANCE) {  // adj + I before the row sums
         if (!has_diag) ++c;
-        s = __dadd_rn(s, 1.0);
+        s = add_rn(s, 1.0);
     }
     cnt[i] = c;
     rowsum[i] = s;
@@ -59,8 +68,8 @@ __global__ void fill_rows(int64_t m, const int64_t* __restrict__ indptr, const i
     const int64_t gi = pt[i];
     const int64_t o0 = row_nnz[i];
     double scale = 1.0;
-    if (mode == MODE_ROWNORM) scale = __ddiv_rn(1.0, fmax(1.0, rowsum[i]));
-    else if (mode == MODE_ENHANCE) scale = __ddiv_rn(1.0, __dadd_rn(rowsum[i], 1e-20));
+    if (mode == MODE_ROWNORM) scale = div_rn(1.0, fmax(1.0, rowsum[i]));
+    else if (mode == MODE_ENHANCE) scale = div_rn(1.0, add_rn(rowsum[i], 1e-20));
     int64_t n = 0;
     bool has_diag = false;
     for (int64_t p = indptr[gi]; p < indptr[gi + 1]; ++p) {
@@ -70,7 +79,7 @@ __global__ void fill_rows(int64_t m, const int64_t* __restrict__ indptr, const i
         double v = binarize ? 1.0 : data[p];
         if (gj == gi) {
             has_diag = true;
-            if (mode == MODE_ENHANCE) v = __dadd_rn(v, 1.0);
+            if (mode == MODE_ENHANCE) v = add_rn(v, 1.0);
         }
         // insert keeping local columns ascending
         int64_t q = n;
@@ -98,8 +107,8 @@ __global__ void fill_rows(int64_t m, const int64_t* __restrict__ indptr, const i
     for (int64_t q = 0; q < n; ++q) {
         coords[2 * (o0 + q)] = static_cast<int32_t>(i);
         double v = values[o0 + q];
-        if (mode != MODE_RAW) v = __dmul_rn(scale, v);
-        if (mode == MODE_ENHANCE && coords[2 * (o0 + q) + 1] == i) v = __dadd_rn(v, __dmul_rn(diag_lambda, v));
+        if (mode != MODE_RAW) v = mul_rn(scale, v);
+        if (mode == MODE_ENHANCE && coords[2 * (o0 + q) + 1] == i) v = add_rn(v, mul_rn(diag_lambda, v));
         values[o0 + q] = v;
     }
 }

@@ -599,6 +599,35 @@ def test_device_validation_supports_bit_exact(dev, golden, li, lam):
         assert np.array_equal(values.cpu().numpy(), v0)
 
 
+def test_device_supports_round_like_scipy_on_weighted_graphs(dev):
+    """Integer-weighted graphs (the Cora loader's multigraph gives weight 2): every reference operation rounds once.
+    The first case is one where a fused multiply-add in `d + lambda * d` is one unit in the last place off
+    (row sum 37, diagonal 5, lambda 0.01); then random graphs, subsets, flavours (tests/fuzz_support.py in small)."""
+    from sparc_amd import utils as U
+    A = sp.csr_matrix(np.array([[4.0, 32.0], [32.0, 0.0]]))
+    coords, values, shape, rowsum = U.DeviceGraph.from_scipy(A, dev).subblock(np.array([0, 1], np.int32), mode=2, diag_lambda=0.01)
+    d = (1.0 / (37.0 + 1e-20)) * 5.0
+    assert rowsum.cpu().numpy()[0] == 37.0 and values.cpu().numpy()[0] == d + 0.01 * d
+    for seed in range(25):
+        rng = np.random.default_rng(seed)
+        n = int(rng.integers(1, 400))
+        A = sp.random(n, n, density=min(1.0, rng.uniform(0.2, 30) / n), random_state=np.random.RandomState(seed), format="csr")
+        A.data[:] = rng.integers(1, 4, A.nnz).astype(np.float64)
+        A = sp.csr_matrix(A + A.T + sp.eye(n))
+        graph = U.DeviceGraph.from_scipy(A, dev)
+        for mode, binarize, lam in ((0, False, -1), (1, True, -1), (2, False, 0.01), (2, True, 0.5)):
+            pt = rng.permutation(n)[:int(rng.integers(1, n + 1))].astype(np.int32)
+            sub = sp.csr_matrix(A[pt, :][:, pt])
+            if binarize:
+                sub = sp.csr_matrix((sub != 0) * 1.0)
+            ref = sub if mode == 0 else O.row_normalize(sub) if mode == 1 else O.row_normalize_diag_enhance(sub, lam)
+            coords, values, shape, _ = graph.subblock(pt, mode=mode, binarize=binarize, diag_lambda=lam)
+            r0, c0, v0, sh0 = O.canonical_support(O.as_support_tuple(sp.csr_matrix(ref)))
+            c = coords.cpu().numpy().reshape(-1, 2)
+            assert tuple(shape) == sh0 and np.array_equal(c[:, 0], r0) and np.array_equal(c[:, 1], c0)
+            assert np.array_equal(values.cpu().numpy(), v0), (seed, mode, binarize, lam)
+
+
 def test_device_degree_arrays_bit_exact(dev, golden):
     from sparc_amd import utils as U
     g = golden("g1_support.npz")
