@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Randomised checks of the floating-point kernels around the Laplacian pass, each against torch / the oracle in float64:
+  mlp     the whole-MLP function (every fused helper kernel and every library fall-back) for random layer widths and row
+          counts, forward and all gradients, against torch.nn float32 layers on the same device;
+  orth    orthonormalisation weights + their application and both backward passes against QR in float64 (oracle);
+  tokens  the token lists against the oracle's sort-based restatement.
+A script (it uses the oracle as a checker), not collected by pytest: python tests/fuzz_float.py [seeds] [first seed]"""
+import os
+import sys
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import sparc_oracle as O  # noqa: E402
+from sparc_amd.ops import OrthApply, OrthWeights, SpectralMLP  # noqa: E402
+from sparc_amd.tokens import spectral_token_lists  # noqa: E402
+
+dev = torch.device("cuda:0")
+worst = {}
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def note(what, e, limit, seed, detail):
+    worst[what] = max(worst.get(what, 0.0), e)
+    if not (e < limit):
+        print(f"MISMATCH {what} seed {seed}: {e:.3g} >= {limit} {detail}", flush=True)
+        sys.exit(1)
+
+
+def check_mlp(seed):
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    nl = int(rng.integers(1, 5))
+    pick = lambda: int(rng.choice([1, 2, 3, 5, 8, 10, 16, 31, 32, 33, 47, 48, 63, 64, 65, 100, 128, 200, 256, 500, 512, 1024, 1100]))
+    dims = [pick() for _ in range(nl + 1)]
+    m = int(rng.choice([1, 2, 63, 64, 65, 255, 256, 257, 1000, 1537, 4097]))
+    x_grad = bool(rng.integers(0, 2))
+    lins = [torch.nn.Linear(a, b).to(dev) for a, b in zip(dims[:-1], dims[1:])]
+    x = torch.randn(m, dims[0], device=dev, requires_grad=x_grad)
+    t = torch.randn(m, dims[-1], device=dev)
+    # the reference is torch's float32 layers on the same device: against float64 the ReLU masks of pre-activations
+    # next to zero flip, for torch's float32 layers exactly as for these kernels (seen: 1e-2 on a first-layer gradient)
+    h = x
+    for lin in lins[:-1]:
+        h = torch.relu(lin(h))
+    ref = torch.tanh(lins[-1](h))
+    params = [p for lin in lins for p in (lin.weight, lin.bias)]
+    wrt = params + ([x] if x_grad else [])
+    rg = torch.autograd.grad((ref * t).sum(), wrt)
+    out = SpectralMLP.apply(x, *params)
+    og = torch.autograd.grad((out * t).sum(), wrt)
+    d = f"dims {dims} m {m} x_grad {x_grad}"
+    note("mlp forward", rel(out.detach().cpu().numpy(), ref.detach().cpu().numpy()), 2e-5, seed, d)
+    for i, (a, b) in enumerate(zip(og, rg)):
+        if float(b.abs().max()) > 0:
+            note("mlp gradient", rel(a.cpu().numpy(), b.cpu().numpy()), 2e-4, seed, d + f" wrt {i}")
+
+
+def check_orth(seed):
+    rng = np.random.default_rng(seed)
+    k = int(rng.integers(1, 65))
+    m1 = int(rng.integers(1, 4000)); m2 = int(rng.integers(max(k, 2) * 3, 6000))
+    Y1 = torch.tensor(rng.standard_normal((m1, k)), dtype=torch.float32)
+    Y2 = torch.tensor(rng.standard_normal((m2, k)) @ (np.eye(k) + 0.3 * rng.standard_normal((k, k))), dtype=torch.float32)
+    T = torch.tensor(rng.standard_normal((m1, k)), dtype=torch.float32)
+    a1, a2 = Y1.double().requires_grad_(True), Y2.double().requires_grad_(True)
+    ref = a1 @ O.orthonorm_weights_qr(a2)
+    r1, r2 = torch.autograd.grad((ref * T.double()).sum(), [a1, a2])
+    b1, b2 = Y1.to(dev).requires_grad_(True), Y2.to(dev).requires_grad_(True)
+    Z = OrthApply.apply(b1, OrthWeights.apply(b2, None, 0))
+    (Z * T.to(dev)).sum().backward()
+    # the gradient through the factorisation loses digits with the condition number of the batch: measured 6e-8 x cond
+    # here, against 6e-7 x cond for the reference's own float32 QR (cond 18 000: 1.1e-3 and 1.1e-2)
+    cond = float(np.linalg.cond(Y2.double().numpy()))
+    d = f"k {k} m1 {m1} m2 {m2} cond {cond:.0f}"
+    note("orth forward", rel(Z.detach().cpu().numpy(), ref.detach().numpy()), 2e-4, seed, d)
+    note("orth grad 1", rel(b1.grad.cpu().numpy(), r1.numpy()), 2e-4, seed, d)
+    note("orth grad 2 / (1 + cond / 1000)", rel(b2.grad.cpu().numpy(), r2.numpy()) / (1.0 + cond / 1000.0), 3e-4, seed, d)
+
+
+def check_tokens(seed):
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(2, 2500)); k = int(rng.integers(1, 33)); nf = int(rng.integers(1, 40)); K = int(rng.integers(1, 15))
+    E = rng.standard_normal((n, k))
+    Fm = rng.standard_normal((n, nf)).astype(np.float32)
+    want = O.spectral_token_lists(E, Fm, K)
+    got = spectral_token_lists(E, Fm, K, device=dev, chunk_rows=int(rng.choice([64, 500, 2048]))).numpy()
+    note("tokens", float(np.abs(got - want).max()), 2e-5, seed, f"n {n} k {k} nf {nf} K {K}")
+
+
+def main():
+    n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    for seed in range(first, first + n_seeds):
+        check_mlp(seed)
+        check_orth(seed)
+        if seed % 3 == 0:
+            check_tokens(seed)
+        if seed % 20 == 0:
+            print(f"seed {seed} ok {worst}", flush=True)
+    print("worst:", worst)
+
+
+if __name__ == "__main__":
+    main()
