@@ -241,6 +241,16 @@ int sparc_orth_apply(int64_t m, int k, const float* Yt, int64_t ld, const float*
 int sparc_orth_weights_bwd(int64_t m, int k, const double* gWo, const double* Rc,
                            const double* Rinv, const double* signs, int mode, float* H,
                            sparc_stream_t stream);
+/* The same backward with H kept in float64, and Z = Yt H accumulated in float64 (Z float32): for an ill-conditioned
+ * orthonormalisation batch the entries of H exceed those of Yt H by many orders of magnitude (they cancel), so the
+ * float32 pair above loses the leading digits of d loss / d Yt (measured: 7e-5 of its largest entry at condition
+ * number 1.7e4, which is 0.3 of the parameter gradient once the MLP's backward has cancelled the large directions;
+ * the reference's QR backward in float32 keeps 4e-4 there).  The autograd functions of the package use this pair. */
+int sparc_orth_weights_bwd_f64(int64_t m, int k, const double* gWo, const double* Rc,
+                               const double* Rinv, const double* signs, int mode, double* H,
+                               sparc_stream_t stream);
+int sparc_orth_apply_f64(int64_t m, int k, const float* Yt, int64_t ld, const double* H,
+                         float* Z, int64_t ldz, sparc_stream_t stream);
 
 /* ---- MLP helpers ---------------------------------------------------------------------------------
  * The SpectralNet MLP is Linear+ReLU x3, Linear+Tanh (src/SpectralTrainer.py:28-39); its wide

@@ -61,6 +61,8 @@ _SIGS = {
     "sparc_orth_weights": (c_int, [c_int64, c_int, P, P, c_int64, P, c_int, P, P, P, P, P, P]),
     "sparc_orth_apply": (c_int, [c_int64, c_int, P, c_int64, P, c_int, P, c_int64, P]),
     "sparc_orth_weights_bwd": (c_int, [c_int64, c_int, P, P, P, P, c_int, P, P]),
+    "sparc_orth_weights_bwd_f64": (c_int, [c_int64, c_int, P, P, P, P, c_int, P, P]),
+    "sparc_orth_apply_f64": (c_int, [c_int64, c_int, P, c_int64, P, P, c_int64, P]),
     "sparc_act_bwd_bias_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "sparc_act_bwd_bias": (c_int, [c_int64, c_int, c_int, P, c_int64, P, c_int64, P, c_int64, P, P, c_size_t, P]),
     "sparc_wgrad_small_workspace_bytes": (c_size_t, [c_int, c_int]),

@@ -393,10 +393,11 @@ __device__ void mm_kk(int k, const double* A, bool ta, const double* B, bool tb,
 
 // Backward of Wo = sqrt(m) S Rc^-1 S through Rc = chol(G)^T:  H = Gbar + Gbar^T, so that
 // d loss / d Yt = Yt H for G = Yt^T Yt.
+template <typename TH>
 __global__ __launch_bounds__(256) void orth_weights_bwd_kernel(int64_t m, int k, const double* __restrict__ gWo,
                                                                const double* __restrict__ Rc, const double* __restrict__ Rinv,
                                                                const double* __restrict__ signs, int mode,
-                                                               float* __restrict__ H) {
+                                                               TH* __restrict__ H) {
     __shared__ double M[SPARC_MAX_K * KLD];   // Rc^-1
     __shared__ double A[SPARC_MAX_K * KLD];
     __shared__ double B[SPARC_MAX_K * KLD];
@@ -430,7 +431,56 @@ __global__ __launch_bounds__(256) void orth_weights_bwd_kernel(int64_t m, int k,
     mm_kk(k, B, false, M, true, A, 1.0);    // A = Gbar = M Phi M^T
     for (int e = tid; e < k * k; e += 256) {
         const int i = e / k, j = e % k;
-        H[e] = static_cast<float>(A[i * KLD + j] + A[j * KLD + i]);
+        H[e] = static_cast<TH>(A[i * KLD + j] + A[j * KLD + i]);
+    }
+}
+
+// Z = Yt H for a float64 H, accumulated in float64 (Z float32): the gradient with respect to the orthonormalisation
+// batch.  For an ill-conditioned batch the entries of H are many orders of magnitude larger than those of the
+// product (they cancel), so rounding H or the partial sums to float32 would cost the gradient its leading digits.
+// 64 rows per block; thread (tr, tc) owns the 4 x 4 outputs rows 4 tr.., columns 4 tc.. and walks the inner
+// dimension with one 16-byte LDS read of Yt (kept transposed) and one 32-byte read of H per step.
+__global__ __launch_bounds__(256) void orth_apply_f64_kernel(int64_t m, int k, const float* __restrict__ Yt, int64_t ld,
+                                                             const double* __restrict__ H, float* __restrict__ Z, int64_t ldz) {
+    __shared__ __attribute__((aligned(16))) double Hs[SPARC_MAX_K][SPARC_MAX_K];
+    __shared__ __attribute__((aligned(16))) float Ys[SPARC_MAX_K][64 + 4];   // [l][row]
+    const int tid = threadIdx.x;
+    const int64_t row0 = static_cast<int64_t>(blockIdx.x) * 64;
+    for (int e = tid; e < SPARC_MAX_K * SPARC_MAX_K; e += 256) {
+        const int i = e / SPARC_MAX_K, j = e % SPARC_MAX_K;
+        Hs[i][j] = (i < k && j < k) ? H[i * k + j] : 0.0;
+    }
+    for (int e = tid; e < 64 * k; e += 256) {
+        const int r = e / k, c = e % k;
+        Ys[c][r] = (row0 + r < m) ? Yt[(row0 + r) * ld + c] : 0.f;
+    }
+    __syncthreads();
+    const int tr = tid >> 4, tc = tid & 15;
+    if (tc * 4 >= k) return;
+    double acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    for (int l = 0; l < k; ++l) {
+        const float4 y = *reinterpret_cast<const float4*>(&Ys[l][tr * 4]);
+        const double2 h0 = *reinterpret_cast<const double2*>(&Hs[l][tc * 4]);
+        const double2 h1 = *reinterpret_cast<const double2*>(&Hs[l][tc * 4 + 2]);
+        const double yv[4] = {static_cast<double>(y.x), static_cast<double>(y.y), static_cast<double>(y.z), static_cast<double>(y.w)};
+        const double hv[4] = {h0.x, h0.y, h1.x, h1.y};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] += yv[i] * hv[j];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t row = row0 + tr * 4 + i;
+        if (row < m) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (tc * 4 + j < k) Z[row * ldz + tc * 4 + j] = static_cast<float>(acc[i][j]);
+        }
     }
 }
 
@@ -585,7 +635,23 @@ extern "C" int sparc_orth_weights(int64_t m, int k, const double* G, const float
 extern "C" int sparc_orth_weights_bwd(int64_t m, int k, const double* gWo, const double* Rc, const double* Rinv,
                                       const double* signs, int mode, float* H, sparc_stream_t stream) {
     if (m <= 0 || k < 1 || k > SPARC_MAX_K || !gWo || !Rc || !Rinv || !signs || !H) return SPARC_ERR_ARG;
-    hipLaunchKernelGGL(orth_weights_bwd_kernel, dim3(1), dim3(256), 0, stream, m, k, gWo, Rc, Rinv, signs, mode, H);
+    hipLaunchKernelGGL(orth_weights_bwd_kernel<float>, dim3(1), dim3(256), 0, stream, m, k, gWo, Rc, Rinv, signs, mode, H);
+    SPARC_CHECK_LAUNCH();
+    return SPARC_OK;
+}
+
+extern "C" int sparc_orth_weights_bwd_f64(int64_t m, int k, const double* gWo, const double* Rc, const double* Rinv,
+                                          const double* signs, int mode, double* H, sparc_stream_t stream) {
+    if (m <= 0 || k < 1 || k > SPARC_MAX_K || !gWo || !Rc || !Rinv || !signs || !H) return SPARC_ERR_ARG;
+    hipLaunchKernelGGL(orth_weights_bwd_kernel<double>, dim3(1), dim3(256), 0, stream, m, k, gWo, Rc, Rinv, signs, mode, H);
+    SPARC_CHECK_LAUNCH();
+    return SPARC_OK;
+}
+
+extern "C" int sparc_orth_apply_f64(int64_t m, int k, const float* Yt, int64_t ld, const double* H, float* Z, int64_t ldz,
+                                    sparc_stream_t stream) {
+    if (m <= 0 || k < 1 || k > SPARC_MAX_K || !Yt || !H || !Z || ld < k || ldz < k) return SPARC_ERR_ARG;
+    hipLaunchKernelGGL(orth_apply_f64_kernel, dim3(static_cast<unsigned>((m + 63) / 64)), dim3(256), 0, stream, m, k, Yt, ld, H, Z, ldz);
     SPARC_CHECK_LAUNCH();
     return SPARC_OK;
 }

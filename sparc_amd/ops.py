@@ -325,11 +325,15 @@ class OrthWeights(torch.autograd.Function):
         m, k = Y.shape
         Rc, Rinv, signs = saved[:k * k], saved[k * k:2 * k * k], saved[2 * k * k:]
         g64 = gWo.detach().to(torch.float64).contiguous()
-        H = torch.empty(k, k, dtype=torch.float32, device=Y.device)
+        # H stays in float64 and Yt H is accumulated in float64: for an ill-conditioned batch the entries of H cancel
+        # down to a product many orders of magnitude smaller
+        H = torch.empty(k, k, dtype=torch.float64, device=Y.device)
+        gY = torch.empty(m, k, dtype=torch.float32, device=Y.device)
         with torch.cuda.device(Y.device):
-            check(lib.sparc_orth_weights_bwd(m, k, _ptr(g64), _ptr(Rc), _ptr(Rinv), _ptr(signs), ctx.mode, _ptr(H),
-                                             _stream()), "sparc_orth_weights_bwd")
-        return orth_apply(Y, H), None, None
+            check(lib.sparc_orth_weights_bwd_f64(m, k, _ptr(g64), _ptr(Rc), _ptr(Rinv), _ptr(signs), ctx.mode, _ptr(H),
+                                                 _stream()), "sparc_orth_weights_bwd_f64")
+            check(lib.sparc_orth_apply_f64(m, k, _ptr(Y), Y.stride(0), _ptr(H), _ptr(gY), k, _stream()), "sparc_orth_apply_f64")
+        return gY, None, None
 
 
 class OrthApply(torch.autograd.Function):
