@@ -24,7 +24,23 @@ def rel(a, b):
 
 
 def batch_of(rng):
-    kind = rng.integers(0, 4)
+    kind = rng.integers(0, 5)
+    if kind == 4:      # loose ends: isolated nodes, rows with a diagonal entry only, no stored diagonal at all, free weights
+        m = int(rng.integers(1, 1400))
+        sizes = [m]
+        D = sp.random(m, m, density=min(1.0, rng.uniform(0.0, 6.0) / m), random_state=np.random.RandomState(int(rng.integers(1 << 30))), format="csr")
+        D.data[:] = rng.uniform(0.2, 3.0, D.nnz)
+        D = sp.triu(D, 1)
+        D = D + D.T
+        keep = rng.random(m) < 0.8                     # a fifth of the nodes lose all their entries
+        Kd = sp.diags(keep.astype(np.float64))
+        D = Kd @ D @ Kd
+        if rng.random() < 0.7:
+            D = D + sp.diags((rng.random(m) < 0.7).astype(np.float64))    # a diagonal entry on most rows
+        D = sp.csr_matrix(D); D.eliminate_zeros()
+        if D.nnz == 0:
+            D = sp.csr_matrix(sp.eye(m))
+        return sizes, D, "raw"
     if kind == 0:      # many small, dense clusters (dense-block territory)
         sizes = [int(x) for x in rng.integers(20, 190, rng.integers(3, 30))]
         m = sum(sizes); start = np.concatenate([[0], np.cumsum(sizes)])
