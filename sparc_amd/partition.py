@@ -201,6 +201,7 @@ def _pack(weights: np.ndarray, k: int, cap: int, conn=None) -> np.ndarray:
                 if load[p] + weights[c] <= cap:
                     part[c] = p
                     load[p] += weights[c]
+                    heapq.heappush(heap, (int(load[p]), p))   # the entry with the old load is skipped when it surfaces
                     placed = True
                     break
         if not placed:
@@ -326,7 +327,27 @@ def kway_partition(n: int, src: torch.Tensor, dst: torch.Tensor, k: int, imbalan
         part, moved = _sweep(part, s_, d_, w_, nw_, low, k, everyone, pull_to=low, rowptr=rp)
         if moved == 0:
             break
-    return _fill_small_parts(part, k, low)
+    return _fill_small_parts(_trim_large_parts(part, k, cap), k, low)
+
+
+def _trim_large_parts(part: torch.Tensor, k: int, cap: int) -> torch.Tensor:
+    """No part above `cap`: the last nodes (in node order) of a part beyond its capacity go to the parts with room,
+    fullest first.  Only reached when the eviction sweeps found no neighbouring part with room (graphs without
+    community structure cut into many parts); k * cap >= n, so there is always room."""
+    sizes = torch.bincount(part, minlength=k)
+    if int(sizes.max()) <= cap:
+        return part
+    order = torch.sort(part, stable=True).indices                      # nodes grouped by part, node order inside
+    start = torch.cumsum(sizes, 0) - sizes
+    rank = torch.arange(part.numel(), device=part.device) - start[part[order]]
+    surplus = order[rank >= cap]                                        # the nodes beyond the capacity of their part
+    room = (cap - sizes).clamp_(min=0)
+    by_room = torch.sort(room, stable=True).indices                    # least room (fullest) first, part order among equals
+    by_room = by_room[room[by_room] > 0]
+    slots = torch.repeat_interleave(by_room, room[by_room])
+    part = part.clone()
+    part[surplus] = slots[:surplus.numel()]
+    return part
 
 
 def _fill_small_parts(part: torch.Tensor, k: int, low: int) -> torch.Tensor:

@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Randomised checks on the GPU of two pieces of host logic around the step:
+  graphs     whole steps replayed as HIP graphs (sparc_amd/stepgraph.py) against the eager trainer, on random graphs,
+             batch counts, widths and k, every (gradient batch, orthogonality batch) pair revisited;
+  partition  the k-way partitioner's contract on random graphs: every node in exactly one part, part sizes within the
+             promised bounds, the same result twice.
+A script, not collected by pytest: python tests/fuzz_train.py [seeds] [first seed]"""
+import os
+import sys
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from sparc_amd import partition as P  # noqa: E402
+from sparc_amd import synth  # noqa: E402
+from sparc_amd.graph import ClusterBatch  # noqa: E402
+from sparc_amd.parallel import ShardedSpectralTrainer  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def check_graphs(seed):
+    rng = np.random.default_rng(seed)
+    ncl = int(rng.integers(4, 25))
+    n = int(rng.integers(40, 250)) * ncl
+    k = int(rng.integers(2, 33))
+    din = int(rng.integers(3, 30))
+    per_batch = int(rng.integers(2, max(3, ncl // 2 + 1)))
+    arch = {"n_layers": 6, "hidden_dim1": int(rng.choice([16, 64, 128])), "hidden_dim2": int(rng.choice([16, 64, 128])),
+            "hidden_dim3": int(rng.choice([16, 32, 64])), "output_dim": k}
+    graph, bounds = synth.planted_cluster_graph(n, int(n * rng.uniform(2, 8)), ncl, dev, seed=seed)
+    nodes_of, _ = synth.cluster_batches(bounds, per_batch, seed=seed, return_clusters=True)
+    nb = min(len(nodes_of), int(rng.integers(1, 4)))
+    runs = {}
+    for mode in (False, True):
+        tr = ShardedSpectralTrainer(arch, din, dev, lr=1e-3, seed=seed, hip_graph=mode)
+        for b in range(nb):
+            coords, values, shp, _ = graph.subblock(nodes_of[b], mode=2, binarize=False, diag_lambda=0.01)
+            tr.add_batch(synth.block_features(nodes_of[b], bounds, din, ncl), ClusterBatch.from_device_coo(shp[0], coords, values).warm(k))
+        r2 = np.random.RandomState(seed)
+        losses = []
+        for s in range(2 * nb * nb):
+            pid, pid_2 = s % nb, (s // nb) % nb
+            losses.append(float(tr.step(pid, pid_2, r2.permutation(tr.batches[pid_2].m)[:k])))
+        runs[mode] = (np.array(losses), torch.cat([p.detach().flatten() for p in tr.params]).cpu().numpy())
+    e = max(rel(runs[True][0], runs[False][0]), rel(runs[True][1], runs[False][1]))
+    if not (np.all(np.isfinite(runs[True][0])) and e < 1e-4):
+        print(f"MISMATCH graphs seed {seed}: n {n} clusters {ncl} batches {nb} k {k}: {e:.2e} {runs[True][0]} {runs[False][0]}", flush=True)
+        sys.exit(1)
+    return e
+
+
+def check_partition(seed):
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(50, 20000))
+    deg = rng.uniform(1.0, 20.0)
+    u = rng.integers(0, n, int(n * deg / 2) + 1); v = rng.integers(0, n, int(n * deg / 2) + 1)
+    keep = u != v
+    key = np.unique(np.concatenate([u[keep] * n + v[keep], v[keep] * n + u[keep]]))
+    src, dst = torch.from_numpy(key // n).to(dev), torch.from_numpy(key % n).to(dev)
+    k = int(rng.integers(2, max(3, min(n // 8, 400))))
+    a = P.kway_partition(n, src, dst, k)
+    b = P.kway_partition(n, src, dst, k)
+    lab = a.cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    ok = lab.shape == (n,) and lab.min() >= 0 and lab.max() < k and np.array_equal(lab, b.cpu().numpy() if torch.is_tensor(b) else np.asarray(b))
+    sizes = np.bincount(lab, minlength=k)
+    ok = ok and sizes.max() <= int(np.ceil(n / k * 1.03)) + 1 and sizes.min() >= n // k // 2
+    if not ok:
+        print(f"MISMATCH partition seed {seed}: n {n} k {k} sizes {sizes.min()}..{sizes.max()} mean {n / k:.1f}", flush=True)
+        sys.exit(1)
+
+
+def main():
+    n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    worst = 0.0
+    for seed in range(first, first + n_seeds):
+        worst = max(worst, check_graphs(seed))
+        check_partition(seed)
+        if seed % 10 == 0:
+            print(f"seed {seed} ok (graphs against eager at worst {worst:.1e})", flush=True)
+    print(f"all within bounds; HIP-graph steps against eager steps at worst {worst:.1e}")
+
+
+if __name__ == "__main__":
+    main()

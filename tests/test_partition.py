@@ -121,3 +121,36 @@ def test_partition_graph_native_on_host_tensors():
     live = coo.data != 0
     assert np.all(where[coo.row[live]] == where[coo.col[live]])
     assert part_adj.diagonal().sum() == 800
+
+
+def test_parts_above_the_capacity_are_trimmed():
+    """Graphs without community structure cut into many parts can leave a part above its capacity after the eviction
+    sweeps (seen: 33 nodes for a capacity of 30); the last step moves the surplus to parts with room."""
+    from sparc_amd.partition import _cap, _trim_large_parts
+    part = torch.tensor([0] * 9 + [1] * 2 + [2] * 4 + [3] * 1)
+    out = _trim_large_parts(part, 4, 5)
+    sizes = torch.bincount(out, minlength=4)
+    assert int(sizes.max()) <= 5 and int(sizes.sum()) == 16
+    assert torch.equal(out[:5], part[:5])                      # the first nodes of the large part stay
+    assert torch.equal(_trim_large_parts(out, 4, 5), out)      # nothing to do the second time
+    # end to end: a random graph, many parts
+    rng = np.random.default_rng(25)
+    n, k = 3000, 120
+    u, v = rng.integers(0, n, 9000), rng.integers(0, n, 9000)
+    keep = u != v
+    key = np.unique(np.concatenate([u[keep] * n + v[keep], v[keep] * n + u[keep]]))
+    lab = kway_partition(n, torch.from_numpy(key // n), torch.from_numpy(key % n), k)
+    sizes = torch.bincount(lab, minlength=k)
+    assert int(sizes.max()) <= _cap(n, k, 0.03) and int(sizes.min()) >= n // k // 2
+
+
+def test_pack_keeps_its_heap_current():
+    """Clusters placed next to their strongest neighbour change a part's load behind the heap's back; the lightest-part
+    fallback must still find every part (a stale heap ran empty: IndexError on a random graph)."""
+    from sparc_amd.partition import _pack
+    weights = np.array([5, 5, 1, 1, 1, 1, 1, 1, 1, 1], dtype=np.int64)
+    conn = {c: {0: 3} for c in range(2, 6)}            # four small clusters pulled to part 0 (room for two: cap 7)
+    part = _pack(weights, 2, 7, conn)
+    assert (part >= 0).all() and part.max() < 2
+    load = np.bincount(part, weights=weights, minlength=2)
+    assert load.sum() == weights.sum() and abs(load[0] - load[1]) <= 2
