@@ -2,7 +2,9 @@
 """Randomised checks of the remaining integer / bit-exact kernels on the GPU, each against an independent formulation:
   csr     sparc_csr_build (ClusterBatch.from_support) against the oracle's SciPy CSR, bit for bit;
   rank    sparc_row_rank_values against numpy's sort, bit for bit;
-  sweep   the partitioner's label-score kernel sweep against the torch formulation of the same sweep, exactly.
+  sweep   the partitioner's label-score kernel sweep against the torch formulation of the same sweep, exactly;
+  gram    sparc_gram (strided operands, every k) against float64 numpy, and sparc_gram_static against it bit for bit;
+  spmm    the plain products of ClusterBatch.spmm (widths, transpose, addend, windowed or not) against SciPy.
 A script (it uses the oracle as a checker), not collected by pytest: python tests/fuzz_misc.py [seeds] [first seed]"""
 import os
 import sys
@@ -133,12 +135,70 @@ def check_sweep(seed):
     return (labels, src, dst, w, nw, n_labels, parity, kw, rp, out_k, moved_k, mean)
 
 
+def check_gram(seed):
+    import ctypes
+    from sparc_amd._lib import lib
+    from sparc_amd.graph import _ptr
+    from sparc_amd.ops import gram
+    rng = np.random.default_rng(seed)
+    m, k = int(rng.integers(1, 30000)), int(rng.integers(1, 65))
+    pad = int(rng.integers(0, 9))
+    A = torch.tensor(rng.standard_normal((m, k + pad)), dtype=torch.float32, device=dev)[:, :k]      # strided rows
+    B = A if rng.random() < 0.5 else torch.tensor(rng.standard_normal((m, k)), dtype=torch.float32, device=dev)
+    G = gram(A, B)
+    want = A.double().cpu().numpy().T @ B.double().cpu().numpy()
+    e = float(np.abs(G.cpu().numpy() - want).max() / max(np.abs(want).max(), 1e-30))
+    if not (e < 1e-12):
+        fail("gram", seed, f"m {m} k {k} error {e:.2e}")
+    G2 = torch.empty_like(G)
+    with torch.cuda.device(dev):
+        rc = lib.sparc_gram_static(m, k, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(G2), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc != 0 or not torch.equal(G, G2):
+        fail("gram_static", seed, f"m {m} k {k} rc {rc}")
+
+
+def check_spmm(seed):
+    rng = np.random.default_rng(seed)
+    ncl = int(rng.integers(1, 9))
+    sizes = [int(x) for x in rng.integers(1, 400, ncl)]
+    m = sum(sizes)
+    lab = np.repeat(np.arange(ncl), sizes)
+    dens = rng.uniform(0.01, 0.2)
+    Pm = np.where(lab[:, None] == lab[None, :], dens, rng.uniform(0, 0.003))
+    A = sp.csr_matrix((rng.random((m, m)) < Pm) * rng.uniform(0.5, 2.0, (m, m)))       # unsymmetric values and pattern
+    if rng.random() < 0.5:
+        A = sp.csr_matrix(A + A.T)
+    A = sp.csr_matrix(A + sp.eye(m))
+    s = O.as_support_tuple(A)
+    b = ClusterBatch.from_support(s, dev, cluster_sizes=sizes)
+    A32, At32 = O.csr_from_support(s)
+    for width in (16, 32, 64, 128):
+        X = rng.standard_normal((m, width)).astype(np.float32)
+        Xd = torch.tensor(X, device=dev)
+        for transpose in (False, True):
+            M = At32 if transpose else A32
+            ref = M @ X.astype(np.float64)
+            variants = [False] + ([True] if width in (32, 64) else [])
+            for tiled in variants:
+                try:
+                    Z = b.spmm(Xd, transpose=transpose, tiled=tiled)
+                except ValueError:
+                    continue            # no tiling for this batch
+                e = float(np.abs(Z.cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-30))
+                Z2 = b.spmm(Xd, add=Xd, transpose=transpose, tiled=tiled)
+                e = max(e, float(np.abs(Z2.cpu().numpy() - (ref + X)).max() / max(np.abs(ref + X).max(), 1e-30)))
+                if not (e < 2e-6):
+                    fail("spmm", seed, f"m {m} width {width} transpose {transpose} tiled {tiled}: {e:.2e}")
+
+
 def main():
     n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     for seed in range(first, first + n_seeds):
         check_csr(seed)
         check_rank(seed)
+        check_gram(seed)
+        check_spmm(seed)
         # the sweep twice with the same cap: kernel against torch
         rng = np.random.default_rng(seed)
         got = check_sweep(seed)
