@@ -54,7 +54,8 @@ def batch_of(rng):
         D.setdiag(0); D.eliminate_zeros()
         D = sp.csr_matrix(D + sp.eye(m))
     else:
-        sizes = [int(x) for x in rng.integers(1, 600 if kind == 1 else 300, rng.integers(1, 14))]
+        many = 80 if os.environ.get("BIG") else 14          # BIG=1: batches of up to 48 k rows (more windows than CUs x 2)
+        sizes = [int(x) for x in rng.integers(1, 600 if kind == 1 else 300, rng.integers(1, many))]
         D = windowed_pattern(rng, sizes, cross_per_row=float(rng.uniform(0, 0.6)), hubs=min(int(rng.integers(0, 8)), sum(sizes)),
                              hub_out=int(rng.integers(1, 8)), dense_tail=bool(rng.integers(0, 2)), big_hubs=0)
         if rng.random() < 0.5:
