@@ -52,3 +52,55 @@ def test_product_package_does_not_import_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src, f
+
+
+def test_every_entry_point_rejects_null_pointers_without_touching_the_device():
+    """Every int-returning entry point, called with null pointers (all sizes zero, then plausible sizes), returns an
+    error code: the checks come before the first launch, so this runs (and must not crash) on a machine without a GPU.
+    A child process makes the calls, so that a crash is reported as one."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes, sys
+sys.path.insert(0, %r)
+from sparc_amd import _lib
+skip = {"sparc_abi_version", "sparc_profile_begin", "sparc_profile_end"}
+for name, (res, args) in _lib._SIGS.items():
+    if res is not ctypes.c_int or name in skip:
+        continue
+    fn = getattr(_lib.lib, name)
+    for fill in (0, 10):
+        vals = []
+        for a in args:
+            if a is ctypes.c_void_p:
+                vals.append(None)
+            elif a is ctypes.c_double:
+                vals.append(0.0)
+            elif a is ctypes.c_size_t:
+                vals.append(0)
+            else:
+                vals.append(fill)
+        print(name, fill, flush=True)
+        rc = fn(*vals)
+        assert rc < 0, (name, fill, rc)
+print("ALL_REJECTED")
+''' % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "ALL_REJECTED" in out.stdout, out.stdout[-600:] + out.stderr[-1500:]
+
+
+def test_out_of_range_widths_are_rejected_before_any_launch():
+    """Entry points whose kernels are built for k (or a narrow width) up to 64 refuse 65 with an argument / size error
+    instead of launching: non-null pointers, plausible row counts, every int argument 65."""
+    from sparc_amd import _lib
+    narrow = ["sparc_gram", "sparc_gram_static", "sparc_orth_weights", "sparc_orth_apply", "sparc_orth_weights_bwd",
+              "sparc_orth_weights_bwd_f64", "sparc_orth_apply_f64", "sparc_act_bwd_bias", "sparc_wgrad_small",
+              "sparc_first_layer_bwd", "sparc_linear_narrow_fwd", "sparc_dgrad_narrow_relu"]
+    for name in narrow:
+        res, args = _lib._SIGS[name]
+        vals = []
+        for a in args:
+            vals.append(4096 if a is ctypes.c_void_p else 0.0 if a is ctypes.c_double else (1 << 30) if a is ctypes.c_size_t
+                        else 65 if a is ctypes.c_int else 100)
+        vals[-1] = None
+        assert getattr(_lib.lib, name)(*vals) in (-1, -4), name
