@@ -779,6 +779,26 @@ def test_token_lists_match_oracle_larger(dev):
     assert np.allclose(got[:, -1, :], Fm.mean(0, keepdims=True), atol=1e-5)
 
 
+def test_token_lists_beyond_the_neighbour_limit(dev):
+    """More nodes than the 16 384 neighbours the reference asks scikit-learn for
+    (implementations/SPARCphormer/utils.py:268-298): the last prefixes stop at 16 384 nodes, not at n.  Checked on a
+    sample of query rows against a direct sort of their distances."""
+    from sparc_amd.tokens import spectral_token_lists
+    rng = np.random.default_rng(3)
+    n, k, nf, K = 17000, 12, 6, 15
+    E = rng.standard_normal((n, k))
+    Fm = rng.standard_normal((n, nf)).astype(np.float32)
+    got = spectral_token_lists(E, Fm, K, device=dev).numpy()
+    rows = rng.choice(n, 200, replace=False)
+    d2 = ((E[rows, None, :] - E[None, :, :]) ** 2).sum(-1)
+    order = np.argsort(d2, axis=1, kind="stable")
+    for j in range(K):
+        e = min(2 ** (j + 1), 2 ** 14, n)
+        want = Fm[order[:, :e]].astype(np.float64).mean(1)
+        assert np.abs(got[rows, j + 1, :] - want).max() < 1e-5, j
+    assert np.array_equal(got[:, 0, :], Fm)
+
+
 def test_facade_fit_predict_with_autoencoder(dev, golden, tmp_path, monkeypatch, capsys):
     """SpectralNet.fit with should_use_ae: autoencoder stage, SpectralNet stage on its codes, predict / embed
     on all nodes (src/SpectralNet.py:25-98), and the results writer."""
