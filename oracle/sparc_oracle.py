@@ -283,8 +283,18 @@ def partition_batches(part_adj: sp.csr_matrix, parts: List[np.ndarray], diag_lam
 # --------------------------------------------------------------------------
 def csr_from_support(support) -> Tuple[sp.csr_matrix, sp.csr_matrix]:
     """Canonical CSR of the float32-cast support and of its transpose."""
-    rows, cols, vals, shape = canonical_support((support[0], np.asarray(support[1], np.float64).astype(np.float32), support[2]))
-    A = sp.csr_matrix((vals.astype(np.float32).astype(np.float64), (rows, cols)), shape=shape)
+    v32 = np.asarray(support[1], np.float64).astype(np.float32)
+    rows, cols, vals, shape = canonical_support((support[0], v32, support[2]))
+    # repeated coordinates: torch's sparse-to-dense (src/SpectralTrainer.py:277) adds the float32 values one after the
+    # other in input order; canonical_support's float64 sum agrees up to two copies, beyond that the order matters
+    coords = np.asarray(support[0]).reshape(-1, 2).astype(np.int64)
+    key = coords[:, 0] * int(shape[1]) + coords[:, 1]
+    uniq = rows.astype(np.int64) * int(shape[1]) + cols
+    if len(key) != len(uniq):
+        acc = np.zeros(len(uniq), dtype=np.float32)
+        np.add.at(acc, np.searchsorted(uniq, key), v32)       # unbuffered: sequential float32 additions
+        vals = acc
+    A = sp.csr_matrix((np.asarray(vals, np.float32).astype(np.float64), (rows, cols)), shape=shape)
     return A, sp.csr_matrix(A.T)
 
 
