@@ -179,12 +179,17 @@ __global__ void prep_rows(int64_t m, const double* __restrict__ racc, const doub
     low_sq -= low_diag * low_diag;
     double rr = a[0] + 2.0 * cross + low_sq;
     rr = rr > 0.0 ? sqrt(rr) : 0.0;
-    rr = rr > 1e-12 ? rr : 1e-12;  // F.normalize(eps=1e-12) clamps the norm
+    // F.normalize(eps=1e-12) clamps the norm.  Every off-diagonal entry carries the 1e-6 background, so only the
+    // single row of a one-node batch gets here: its row is exactly zero and stays zero after the division, which
+    // 1 / rho = 0 reproduces (the rounding residue of the row's terms times 1e12 would not)
+    const bool clamped = !(rr > 1e-12);
+    rr = clamped ? 1e-12 : rr;
     const double gi = sdiag[i] + low_diag;
     rho[i] = rr;
     g[i] = gi;
-    x[i] = 1.0 / rr;
-    d[i] = (((r[i] + r2[i] + r3[i]) - sdiag[i]) + ((uc[0] * vt1[0] + uc[1] * vt1[1] + uc[2] * vt1[2]) - low_diag)) / rr;
+    x[i] = clamped ? 0.0 : 1.0 / rr;
+    d[i] = clamped ? 0.0
+                   : (((r[i] + r2[i] + r3[i]) - sdiag[i]) + ((uc[0] * vt1[0] + uc[1] * vt1[1] + uc[2] * vt1[2]) - low_diag)) / rr;
 }
 
 // utx = U^T x (3 sums)

@@ -20,6 +20,8 @@ dev = torch.device("cuda:0")
 
 def rel(a, b):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    if np.isnan(a).all() and np.isnan(b).all():
+        return 0.0          # a single-node batch: W is the 1 x 1 zero matrix and the loss 0 / 0, for the reference too
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
@@ -113,6 +115,24 @@ def main():
             if not (e < 1e-4):
                 print("MISMATCH", line, flush=True)
                 sys.exit(1)
+        if m <= 500:   # both branches of the loss module and autograd through it, against the dense float64 restatement
+            from sparc_amd.SpectralTrainer import SpectralNetLoss
+            ClusterBatch.use_tiles = ClusterBatch.use_blocks = ClusterBatch.use_pattern = True
+            b = ClusterBatch.from_support(s, dev, cluster_sizes=sizes)
+            Wd = O.valid_affinity(O.support_to_dense(s, torch.float64))
+            Yd = Y.detach().cpu().double().requires_grad_(True)
+            for norm in (True, False):
+                want = O.spectral_loss(Wd, Yd, norm)
+                (gw,) = torch.autograd.grad(want, Yd)
+                Yg = Y.detach().clone().requires_grad_(True)
+                got = SpectralNetLoss()(b, Yg, is_normalized=norm)
+                got.backward()
+                e = max(rel(got.item(), want.item()), rel(Yg.grad.cpu().numpy(), gw.numpy()) if float(gw.abs().max()) > 0 else 0.0)
+                worst["dense, normalised" if norm else "dense, plain"] = max(worst.get("dense, normalised" if norm else "dense, plain", 0.0), e)
+                line += f" dense{'N' if norm else 'P'} {e:.1e}"
+                if not (e < 1e-4):
+                    print("MISMATCH", line, flush=True)
+                    sys.exit(1)
         print(line, flush=True)
     print("worst:", worst)
 

@@ -193,6 +193,26 @@ def test_lap_isolated_nodes_and_empty_rows(dev):
     assert rel(grad.cpu().numpy(), gd.numpy()) < TOL
 
 
+def test_one_node_batch_behaves_like_the_reference(dev):
+    """A batch of one node: W is the 1 x 1 zero matrix (its only entry is the removed diagonal), so the plain loss is
+    exactly zero with a zero gradient, and the normalised loss divides by sqrt(0): nan, for the reference as well
+    (src/SpectralTrainer.py:130-137)."""
+    from sparc_amd.SpectralTrainer import SpectralNetLoss
+    from sparc_amd.graph import ClusterBatch
+    s = O.as_support_tuple(sp.csr_matrix(np.eye(1)))
+    b = ClusterBatch.from_support(s, dev)
+    W = O.valid_affinity(O.support_to_dense(s, torch.float64))
+    assert float(W.abs().max()) == 0.0
+    for k in (3, 31):
+        Y = torch.randn(1, k, device=dev, requires_grad=True)
+        plain = SpectralNetLoss()(b, Y, is_normalized=False)
+        plain.backward()
+        assert float(plain) == 0.0 == float(O.spectral_loss(W, Y.detach().cpu().double(), False))
+        assert float(Y.grad.abs().max()) == 0.0
+        assert torch.isnan(SpectralNetLoss()(b, Y.detach(), is_normalized=True))
+        assert torch.isnan(O.spectral_loss(W, Y.detach().cpu().double(), True))
+
+
 def test_lap_permutation_invariance_large(dev):
     """Size-independent property at a batch size the dense oracle cannot reach quickly:
     relabelling the nodes leaves the loss unchanged and permutes the gradient."""
