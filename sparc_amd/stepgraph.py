@@ -7,6 +7,11 @@ the caller), so the step -- forward of both batches, orthonormalisation, Laplaci
 is captured once per (gradient batch, orthogonality batch) pair and replayed with one launch.  What changes from
 step to step is handed over in static device buffers: the k leading rows of the orthogonality batch's
 permutation (src/SpectralTrainer.py:218-223) and the learning rate.
+
+A pair's first visit costs an eager step plus the capture, and there are (number of batches) squared pairs, so the
+mode pays where the batches are few and visited often (Cora: one, PubMed: a handful).  With twelve Amazon2M-shape
+batches most of the first hundred steps meet a new pair and the run is slower than eager (7.5 against 4.3 ms per
+step); MAX_GRAPHS bounds what is captured, later new pairs run eagerly.
 """
 from __future__ import annotations
 
@@ -21,6 +26,7 @@ class GraphedSteps:
     must be capturable (torch.optim.Adam(..., capturable=True)) with its learning rate in a device tensor."""
 
     RING = 8   # pinned staging buffers for the permutation heads: the host may run this many steps ahead
+    MAX_GRAPHS = 64   # pairs captured at most; a pair met after that runs eagerly every time
 
     def __init__(self, net, criterion, optimizer, features, batches, k: int, device):
         self.net, self.criterion, self.optimizer = net, criterion, optimizer
@@ -65,6 +71,10 @@ class GraphedSteps:
         self._stage(top_idx)
         key = (pid, pid_2)
         hit = self.graphs.get(key)
+        if hit is None and len(self.graphs) >= self.MAX_GRAPHS:
+            loss = self._eager(pid, pid_2)
+            self.net.orthonorm_weights = self.orth
+            return loss.clone()
         if hit is None:
             # the pair's first step runs eagerly on a side stream (it sizes the workspace and configures the
             # kernels); the capture that follows records the pair's NEXT step without executing it

@@ -904,10 +904,11 @@ def test_cora_batch_matches_reference(dev, golden):
             ClusterBatch.use_tiles = True
 
 
-def test_hip_graph_steps_match_eager_steps(dev):
+def test_hip_graph_steps_match_eager_steps(dev, monkeypatch):
     """Whole steps replayed as HIP graphs (sparc_amd/stepgraph.py) follow the eager trainer: same losses and
     weights over eight steps that revisit every (gradient batch, orthogonality batch) pair of two batches,
-    with a different permutation head every step."""
+    with a different permutation head every step; likewise when only two of the four pairs may be captured and
+    the others keep running eagerly between the replays."""
     from sparc_amd import synth
     from sparc_amd.graph import ClusterBatch
     from sparc_amd.parallel import ShardedSpectralTrainer
@@ -915,9 +916,11 @@ def test_hip_graph_steps_match_eager_steps(dev):
     arch = {"n_layers": 6, "hidden_dim1": 64, "hidden_dim2": 64, "hidden_dim3": 32, "output_dim": k}
     graph, bounds = synth.planted_cluster_graph(3000, 12000, 12, dev, seed=3)
     nodes_of, cluster_ids = synth.cluster_batches(bounds, 6, seed=0, return_clusters=True)
+    from sparc_amd.stepgraph import GraphedSteps
     runs = {}
-    for mode in (False, True):
-        tr = ShardedSpectralTrainer(arch, din, dev, lr=1e-3, seed=5, hip_graph=mode)
+    for mode in (False, True, "capped"):   # capped: two pairs captured at most, the other two stay eager
+        monkeypatch.setattr(GraphedSteps, "MAX_GRAPHS", 2 if mode == "capped" else 64)
+        tr = ShardedSpectralTrainer(arch, din, dev, lr=1e-3, seed=5, hip_graph=bool(mode))
         for b in range(2):
             coords, values, shp, _ = graph.subblock(nodes_of[b], mode=2, binarize=False, diag_lambda=0.01)
             tr.add_batch(synth.block_features(nodes_of[b], bounds, din, 12),
@@ -929,10 +932,12 @@ def test_hip_graph_steps_match_eager_steps(dev):
             head = rng.permutation(tr.batches[pid_2].m)[:k]
             losses.append(float(tr.step(pid, pid_2, head)))
         runs[mode] = (np.array(losses), torch.cat([p.detach().flatten() for p in tr.params]).cpu().numpy())
-    assert len(tr._graphed.graphs) == 4
-    assert np.all(np.isfinite(runs[True][0]))
-    assert rel(runs[True][0], runs[False][0]) < 1e-5, (runs[True][0], runs[False][0])
-    assert rel(runs[True][1], runs[False][1]) < 1e-5
+        if mode:
+            assert len(tr._graphed.graphs) == (2 if mode == "capped" else 4)
+    for mode in (True, "capped"):
+        assert np.all(np.isfinite(runs[mode][0]))
+        assert rel(runs[mode][0], runs[False][0]) < 1e-5, (mode, runs[mode][0], runs[False][0])
+        assert rel(runs[mode][1], runs[False][1]) < 1e-5
 
 
 def test_training_separates_planted_clusters(dev, tmp_path, monkeypatch, capsys):
