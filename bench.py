@@ -244,11 +244,14 @@ def main():
         alg_bytes += 2 * a_b
         moved_bytes += 2 * m_b
         losses.append(loss)
+    t_host = time.perf_counter() - t0     # the host's share: how long it took to enqueue the steps
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    log(f"[bench] rank {rank}: host enqueued {args.steps} steps in {t_host * 1e3 / args.steps:.2f} ms/step, "
+        f"device finished them in {elapsed * 1e3 / args.steps:.2f} ms/step")
     tot_ms, launches = ctypes.c_double(0.0), ctypes.c_int64(0)
     if args.hip_graph:       # the same event bracket around the inner passes of eager calls on batch 0
         b0 = trainer.batches[0]

@@ -5,6 +5,7 @@ libsparc_hip.so.
 """
 from __future__ import annotations
 
+import numpy as np
 import torch
 
 from ._lib import check, lib
@@ -271,6 +272,49 @@ class SplitRows(torch.autograd.Function):
         return torch.cat([g1, g2], dim=0), None
 
 
+class _IndexStaging:
+    """Pinned host buffers through which short index lists reach the device without stopping the host: a copy from
+    pageable memory returns only when the stream has got to it, i.e. after every kernel enqueued before it, and a
+    training step hands over the k leading rows of its permutation in the middle of the forward pass."""
+    RING, WIDTH = 16, 64
+
+    def __init__(self):
+        self.host = [torch.empty(self.WIDTH, dtype=torch.int32).pin_memory() for _ in range(self.RING)]
+        self.done = [None] * self.RING     # event after the copy out of each buffer
+        self.turn = 0
+
+    def send(self, values: np.ndarray, dev) -> torch.Tensor:
+        slot = self.turn % self.RING
+        self.turn += 1
+        if self.done[slot] is not None:
+            self.done[slot].synchronize()   # RING copies back: long finished unless the host runs that far ahead
+        n = values.shape[0]
+        self.host[slot].numpy()[:n] = values
+        out = torch.empty(n, dtype=torch.int32, device=dev)
+        out.copy_(self.host[slot][:n], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        self.done[slot] = ev
+        return out
+
+
+_index_staging = {}
+
+
+def _index_to_device(idx, dev) -> torch.Tensor:
+    """int32 device copy of a short index list; host lists of up to 64 entries travel asynchronously."""
+    if torch.is_tensor(idx) and idx.device == dev:
+        return idx.to(torch.int32).contiguous()
+    arr = np.ascontiguousarray(idx.cpu().numpy() if torch.is_tensor(idx) else np.asarray(idx)).astype(np.int32, copy=False)
+    if arr.ndim != 1 or arr.shape[0] > _IndexStaging.WIDTH or torch.cuda.is_current_stream_capturing():
+        return torch.as_tensor(arr, device=dev)
+    key = dev.index or 0
+    if key not in _index_staging:
+        _index_staging[key] = _IndexStaging()
+    with torch.cuda.device(dev):
+        return _index_staging[key].send(arr, dev)
+
+
 class OrthWeights(torch.autograd.Function):
     """Yt [m, k] -> orthonormalisation weights [k, k]  (src/SpectralTrainer.py:42-70)."""
 
@@ -304,7 +348,7 @@ class OrthWeights(torch.autograd.Function):
         info = torch.zeros(1, dtype=torch.int32, device=dev)
         tidx = None
         if top_idx is not None:
-            tidx = torch.as_tensor(top_idx, device=dev).to(torch.int32).contiguous()
+            tidx = _index_to_device(top_idx, dev)
             if tidx.numel() < k:  # batches with fewer than k rows: pad with out-of-range rows (read as zero)
                 tidx = torch.cat([tidx, torch.full((k - tidx.numel(),), m, dtype=torch.int32, device=dev)])
         with torch.cuda.device(dev):

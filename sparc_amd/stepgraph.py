@@ -10,7 +10,7 @@ permutation (src/SpectralTrainer.py:218-223) and the learning rate.
 
 A pair's first visit costs an eager step plus the capture, and there are (number of batches) squared pairs, so the
 mode pays where the batches are few and visited often (Cora: one, PubMed: a handful).  With twelve Amazon2M-shape
-batches most of the first hundred steps meet a new pair and the run is slower than eager (7.5 against 4.3 ms per
+batches most of the first hundred steps meet a new pair and the run is slower than eager (7.5 against 4.2 ms per
 step); MAX_GRAPHS bounds what is captured, later new pairs run eagerly.
 """
 from __future__ import annotations
