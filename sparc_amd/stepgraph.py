@@ -1,7 +1,8 @@
 """Whole training steps replayed as HIP graphs.
 
 A SpectralNet step on a small batch (Cora: 2.4 k rows, PubMed-shape: 6 k) is about 45 kernel launches of a few
-microseconds each, so the host's launch rate bounds it.  Every launch of the step is stream-ordered and
+microseconds each, so a host that cannot launch that fast bounds it (the hosts measured so far can: replay and eager
+step take the same time there).  Every launch of the step is stream-ordered and
 allocation-free once warm (the kernels of libsparc_hip.so take the stream as an argument and a workspace from
 the caller), so the step -- forward of both batches, orthonormalisation, Laplacian chain, backward, fused Adam --
 is captured once per (gradient batch, orthogonality batch) pair and replayed with one launch.  What changes from
