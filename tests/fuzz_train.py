@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised checks on the GPU of two pieces of host logic around the step:
-  graphs     whole steps replayed as HIP graphs (sparc_amd/stepgraph.py) against the eager trainer, on random graphs,
-             batch counts, widths and k, every (gradient batch, orthogonality batch) pair revisited;
+  graphs     whole steps replayed as HIP graphs (sparc_amd/stepgraph.py) against the eager trainer (bit for bit with the
+             same optimiser), on random graphs, batch counts, widths and k, every (gradient batch, orthogonality batch)
+             pair revisited;
   partition  the k-way partitioner's contract on random graphs: every node in exactly one part, part sizes within the
              promised bounds, the same result twice.
 A script, not collected by pytest: python tests/fuzz_train.py [seeds] [first seed]"""
@@ -38,8 +39,10 @@ def check_graphs(seed):
     nodes_of, _ = synth.cluster_batches(bounds, per_batch, seed=seed, return_clusters=True)
     nb = min(len(nodes_of), int(rng.integers(1, 4)))
     runs = {}
-    for mode in (False, True):
-        tr = ShardedSpectralTrainer(arch, din, dev, lr=1e-3, seed=seed, hip_graph=mode)
+    for mode in (False, "capturable", True):   # eager; eager with the optimiser the graphs need; graphs
+        tr = ShardedSpectralTrainer(arch, din, dev, lr=1e-3, seed=seed, hip_graph=(mode is True))
+        if mode == "capturable":
+            tr.optimizer = torch.optim.Adam(tr.net.parameters(), lr=torch.tensor(1e-3, device=dev), fused=True, capturable=True)
         for b in range(nb):
             coords, values, shp, _ = graph.subblock(nodes_of[b], mode=2, binarize=False, diag_lambda=0.01)
             tr.add_batch(synth.block_features(nodes_of[b], bounds, din, ncl), ClusterBatch.from_device_coo(shp[0], coords, values).warm(k))
@@ -49,13 +52,16 @@ def check_graphs(seed):
             pid, pid_2 = s % nb, (s // nb) % nb
             losses.append(float(tr.step(pid, pid_2, r2.permutation(tr.batches[pid_2].m)[:k])))
         runs[mode] = (np.array(losses), torch.cat([p.detach().flatten() for p in tr.params]).cpu().numpy())
+    # captured and replayed steps are the eager steps bit for bit once both use the capturable Adam (which takes its
+    # learning rate from a tensor and rounds the step size differently from the default one)
+    exact = np.array_equal(runs[True][0], runs["capturable"][0]) and np.array_equal(runs[True][1], runs["capturable"][1])
     e = max(rel(runs[True][0], runs[False][0]), rel(runs[True][1], runs[False][1]))
     step_e = np.abs(runs[True][0] - runs[False][0]) / np.abs(runs[False][0])
-    # rounding differences (the captured Adam takes its learning rate from a tensor) grow along a trajectory: the first
-    # steps must agree to rounding; ill-conditioned starts (losses of millions) then drift apart by up to 4e-3 in eight steps
-    if not (np.all(np.isfinite(runs[True][0])) and e < 5e-2 and step_e[0] < 1e-6 and step_e[:2].max() < 2e-5):
+    # against the default Adam the first steps agree to rounding; that rounding then grows along the trajectory
+    # (ill-conditioned starts with losses of millions: up to 0.2 of a later step's loss), so only the start is bounded
+    if not (exact and np.all(np.isfinite(runs[True][0])) and step_e[0] < 1e-6 and step_e[:2].max() < 2e-5):
         print("per-step relative differences of the loss:", " ".join(f"{x:.1e}" for x in step_e), flush=True)
-        print(f"MISMATCH graphs seed {seed}: n {n} clusters {ncl} batches {nb} k {k}: {e:.2e} {runs[True][0]} {runs[False][0]}", flush=True)
+        print(f"MISMATCH graphs seed {seed}: n {n} clusters {ncl} batches {nb} k {k}: exact {exact} {e:.2e} {runs[True][0]} {runs[False][0]}", flush=True)
         sys.exit(1)
     return e
 
@@ -89,8 +95,8 @@ def main():
         worst = max(worst, check_graphs(seed))
         check_partition(seed)
         if seed % 10 == 0:
-            print(f"seed {seed} ok (graphs against eager at worst {worst:.1e})", flush=True)
-    print(f"all within bounds; HIP-graph steps against eager steps at worst {worst:.1e}")
+            print(f"seed {seed} ok (graphs bit-equal to eager steps with the same Adam; against the default Adam at worst {worst:.1e})", flush=True)
+    print(f"all within bounds; HIP-graph steps bit-equal to eager steps with the same Adam (against the default Adam at worst {worst:.1e})")
 
 
 if __name__ == "__main__":

@@ -918,9 +918,11 @@ def test_hip_graph_steps_match_eager_steps(dev, monkeypatch):
     nodes_of, cluster_ids = synth.cluster_batches(bounds, 6, seed=0, return_clusters=True)
     from sparc_amd.stepgraph import GraphedSteps
     runs = {}
-    for mode in (False, True, "capped"):   # capped: two pairs captured at most, the other two stay eager
+    for mode in (False, "same optimiser", True, "capped"):   # capped: two pairs captured at most, the other two stay eager
         monkeypatch.setattr(GraphedSteps, "MAX_GRAPHS", 2 if mode == "capped" else 64)
-        tr = ShardedSpectralTrainer(arch, din, dev, lr=1e-3, seed=5, hip_graph=bool(mode))
+        tr = ShardedSpectralTrainer(arch, din, dev, lr=1e-3, seed=5, hip_graph=mode in (True, "capped"))
+        if mode == "same optimiser":   # eager steps with the Adam variant the graphs need (learning rate in a tensor)
+            tr.optimizer = torch.optim.Adam(tr.net.parameters(), lr=torch.tensor(1e-3, device=dev), fused=True, capturable=True)
         for b in range(2):
             coords, values, shp, _ = graph.subblock(nodes_of[b], mode=2, binarize=False, diag_lambda=0.01)
             tr.add_batch(synth.block_features(nodes_of[b], bounds, din, 12),
@@ -932,12 +934,15 @@ def test_hip_graph_steps_match_eager_steps(dev, monkeypatch):
             head = rng.permutation(tr.batches[pid_2].m)[:k]
             losses.append(float(tr.step(pid, pid_2, head)))
         runs[mode] = (np.array(losses), torch.cat([p.detach().flatten() for p in tr.params]).cpu().numpy())
-        if mode:
+        if mode in (True, "capped"):
             assert len(tr._graphed.graphs) == (2 if mode == "capped" else 4)
     for mode in (True, "capped"):
         assert np.all(np.isfinite(runs[mode][0]))
         assert rel(runs[mode][0], runs[False][0]) < 1e-5, (mode, runs[mode][0], runs[False][0])
         assert rel(runs[mode][1], runs[False][1]) < 1e-5
+        # with the same optimiser arithmetic the replayed steps are the eager steps bit for bit
+        assert np.array_equal(runs[mode][0], runs["same optimiser"][0])
+        assert np.array_equal(runs[mode][1], runs["same optimiser"][1])
 
 
 def test_training_separates_planted_clusters(dev, tmp_path, monkeypatch, capsys):
