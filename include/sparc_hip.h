@@ -185,7 +185,9 @@ int sparc_blocks_spmm(int64_t m, int width, const sparc_blocks_t* blocks, const 
  * width in {16, 32, 64, 128}; pass the mirrored values as `val` for A^T X.  With a tiling
  * (dual = 0, kp = width = 16 vec: one slab, which is the row-major operand itself) the windowed
  * kernel runs and takes the values from the tiling's streams (built from the mirrored values
- * for A^T X).  Exposed for roofline measurements on whole graphs. */
+ * for A^T X).  X0 may be Z itself (a row's own operand is read before the row is written, by the
+ * lanes that write it), which accumulates a product pass by pass; X must not overlap Z.  Exposed
+ * for roofline measurements on whole graphs. */
 int sparc_spmm(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* colidx,
                const float* val, int width, const float* X, const float* X0, float* Z,
                const sparc_tiling_t* tiling, sparc_stream_t stream);

@@ -11,10 +11,12 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _spmm(lib, n, rowptr, colidx, val, X):
-    Z = torch.empty_like(X)
+def _spmm(lib, n, rowptr, colidx, val, X, into=None):
+    """Z = A X, or into += A X in place (the own-row operand X0 of the C ABI is the result itself)."""
+    Z = torch.empty_like(X) if into is None else into
     P = lambda t: ctypes.c_void_p(t.data_ptr())
-    rc = lib.sparc_spmm(n, int(colidx.numel()), P(rowptr), P(colidx), P(val), int(X.shape[1]), P(X), None, P(Z), None,
+    rc = lib.sparc_spmm(n, int(colidx.numel()), P(rowptr), P(colidx), P(val), int(X.shape[1]), P(X),
+                        None if into is None else P(into), P(Z), None,
                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0
     return Z
@@ -47,3 +49,36 @@ def test_rmat_product_matches_scipy_in_both_orders(width):
     val2 = torch.from_numpy(Ap.data.astype(np.float32)).to(dev)
     Z2 = _spmm(lib, n, rp2, ci2, val2, X[perm].contiguous()).cpu().numpy()
     assert (np.abs(Z2 - ref[perm.cpu().numpy()]) / scale[perm.cpu().numpy()]).max() < 1e-5
+
+
+def test_product_accumulated_in_place_over_column_blocks():
+    """The whole-graph product as one pass per block of source nodes, the result accumulated in place (X0 = Z):
+    what tools/spmm_stress.py's rmat-blocked case times.  Blocks without entries for most rows, an empty block,
+    and rows that are empty in every block included."""
+    from sparc_amd import synth
+    from sparc_amd._lib import lib
+    dev = torch.device("cuda:0")
+    n, e, width = 6000, 60000, 64
+    rowptr, colidx = synth.rmat_graph(n, e, dev, seed=5)
+    val = torch.rand(colidx.numel(), device=dev) + 0.5
+    A = sp.csr_matrix((val.cpu().numpy(), colidx.cpu().numpy(), rowptr.cpu().numpy()), shape=(n, n)).tolil()
+    A[100:140, :] = 0                      # rows without entries
+    A[:, 4096:5120] = 0                    # a block of source nodes nobody points to
+    A = A.tocsr()
+    A.eliminate_zeros()
+    A.sort_indices()
+    X = torch.randn(n, width, device=dev)
+    ref = A.astype(np.float64) @ X.cpu().numpy().astype(np.float64)
+    Z, empty_blocks = None, 0
+    for lo in range(0, n, 1024):
+        mask = (A.indices >= lo) & (A.indices < lo + 1024)
+        rows = np.repeat(np.arange(n), np.diff(A.indptr))[mask]
+        rp = np.zeros(n + 1, np.int64)
+        rp[1:] = np.cumsum(np.bincount(rows, minlength=n))
+        args = (torch.from_numpy(rp).to(dev), torch.from_numpy(A.indices[mask].astype(np.int32)).to(dev),
+                torch.from_numpy(A.data[mask].astype(np.float32)).to(dev))
+        empty_blocks += int(args[1].numel() == 0)   # an empty pattern is a valid argument (null entry pointers)
+        Z = _spmm(lib, n, *args, X, into=Z) if Z is not None else _spmm(lib, n, *args, X)
+    scale = np.maximum(np.abs(ref).max(axis=1, keepdims=True), 1e-3)
+    assert (np.abs(Z.cpu().numpy() - ref) / scale).max() < 1e-5
+    assert np.all(Z.cpu().numpy()[100:140] == 0) and empty_blocks == 1
