@@ -2,6 +2,7 @@
 // the activation derivative fused with the bias gradient, and the weight gradient of the
 // narrow output layer.  The wide products stay library GEMMs.
 #include "common.h"
+#include <mutex>
 
 namespace {
 
@@ -255,14 +256,15 @@ __global__ __launch_bounds__(256) void wgrad_finish(int nchunks, int n_out, int 
 // row 16 a + i from LDS; every MFMA step uses one k of the run on both operands (the order of k inside
 // the sum is free).  Register q of the result is out[row 4 kk + q][16 a + i].
 template <int NT, int ACT>
-__global__ __launch_bounds__(512) void linear_narrow_fwd_kernel(int64_t m, int K, int n_out, const float* __restrict__ x,
+__global__ __launch_bounds__(1024) void linear_narrow_fwd_kernel(int64_t m, int K, int n_out, const float* __restrict__ x,
                                                                 int64_t ldx, const float* __restrict__ W,
                                                                 const float* __restrict__ b, float* __restrict__ out,
                                                                 int64_t ldo) {
     extern __shared__ float Ws[];  // [NT * 16][K + 4]
     const int KS = K + 4;
     const int k4 = K >> 2;
-    for (int e = threadIdx.x; e < NT * 16 * k4; e += 512) {
+    const int nw = blockDim.x >> 6;   // waves of the workgroup: 8, 12 or 16, whichever spreads the row tiles best
+    for (int e = threadIdx.x; e < NT * 16 * k4; e += blockDim.x) {
         const int n = e / k4, c4 = e - n * k4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (n < n_out) v = *reinterpret_cast<const float4*>(W + (int64_t)n * K + 4 * c4);
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(512) void linear_narrow_fwd_kernel(int64_t m, int K
     float bias[NT];
 #pragma unroll
     for (int a = 0; a < NT; ++a) bias[a] = (16 * a + i < n_out) ? b[16 * a + i] : 0.f;
-    for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 8) {
+    for (int64_t tile = (int64_t)blockIdx.x * nw + wave; tile < ntiles; tile += (int64_t)gridDim.x * nw) {
         const int64_t r = min(tile * 16 + i, m - 1);
         // 64 consecutive k per group: lane (i, kk) reads x[row i][64 T + 16 kk .. + 15] (64 contiguous
         // bytes, a whole 256-byte line per row and wave instruction) and the same k of W's rows
@@ -539,6 +541,25 @@ extern "C" int sparc_first_layer_bwd(int64_t m, int din, int n, const float* x, 
     return wgrad_launch(true, m, din, din + 1, n, x, ldx, g, ldg, h, ldh, dWt_db, ws, stream);
 }
 
+namespace {
+// Per device and per instantiation: allow the large dynamic LDS allocation (the weight matrix of the layer).
+template <int NT, int ACT>
+int configure_narrow_fwd() {
+    static std::mutex mu;
+    static bool done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SPARC_ERR_LAUNCH;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!done[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_narrow_fwd_kernel<NT, ACT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+            return SPARC_ERR_LAUNCH;
+        done[dev] = true;
+    }
+    return SPARC_OK;
+}
+}  // namespace
+
 extern "C" int sparc_linear_narrow_fwd(int64_t m, int K, int n_out, int act, const float* x, int64_t ldx, const float* W,
                                        const float* b, float* out, int64_t ldo, sparc_stream_t stream) {
     if (m < 0 || K <= 0 || K % 16 != 0 || n_out <= 0 || n_out > SPARC_MAX_K || (act != ACT_RELU && act != ACT_TANH && act != 2) ||
@@ -549,18 +570,20 @@ extern "C" int sparc_linear_narrow_fwd(int64_t m, int K, int n_out, int act, con
     if (lds > 150 * 1024) return SPARC_ERR_ARG;   // the weight matrix must fit the LDS of one CU
     if (m == 0) return SPARC_OK;
     const int64_t ntiles = (m + 15) / 16;
-    int64_t nb = (ntiles + 7) / 8;
+    // one workgroup per CU (the weights fill its LDS); the matrix pipe of a SIMD serves waves / 4 of its waves, each
+    // with ceil(tiles / (256 * waves)) row tiles: take the wave count with the fewest tiles per SIMD
+    int waves = 8;
+    int64_t best = 0;
+    for (int w = 8; w <= 16; w += 4) {
+        const int64_t per_simd = ((ntiles + 256 * w - 1) / (256 * w)) * (w / 4);
+        if (w == 8 || per_simd < best) { best = per_simd; waves = w; }
+    }
+    int64_t nb = (ntiles + waves - 1) / waves;
     if (nb > 256) nb = 256;
-    dim3 grid((unsigned)nb), block(512);
+    dim3 grid((unsigned)nb), block(64 * waves);
 #define SPARC_FWD(NT_, A_)                                                                                               \
     do {                                                                                                                 \
-        static bool configured = false;                                                                                  \
-        if (!configured) {                                                                                               \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_narrow_fwd_kernel<NT_, A_>),                   \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)              \
-                return SPARC_ERR_LAUNCH;                                                                                 \
-            configured = true;                                                                                           \
-        }                                                                                                                \
+        if (configure_narrow_fwd<NT_, A_>() != SPARC_OK) return SPARC_ERR_LAUNCH;                                        \
         hipLaunchKernelGGL((linear_narrow_fwd_kernel<NT_, A_>), grid, block, lds, stream, m, K, n_out, x, ldx, W, b, out, ldo); \
     } while (0)
 #define SPARC_FWD_ACT(NT_)                                    \
