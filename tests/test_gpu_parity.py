@@ -429,6 +429,40 @@ def test_spectral_mlp_matches_torch_layers(dev, dims, x_grad):
         assert a.shape == b.shape and rel(a.cpu().numpy(), b.cpu().numpy()) < 1e-4
 
 
+def test_weight_gradient_summed_in_parts(dev, monkeypatch):
+    """Long batches sum the weight gradient of a wide layer whose result is small in four parts as one batched
+    product (ops.wgrad_wide): against float64, with rows left over after the four parts, and through the whole
+    MLP's backward against the same backward without the split."""
+    from sparc_amd import ops
+    torch.manual_seed(8)
+    m = 16384 + 4 * 611 + 3
+    g, x = torch.randn(m, 128, device=dev), torch.randn(m, 192, device=dev)
+    ref = (g.double().t() @ x.double()).cpu().numpy()
+    calls = []
+    real_bmm = torch.bmm
+    monkeypatch.setattr(torch, "bmm", lambda *a, **k: (calls.append(a[0].shape), real_bmm(*a, **k))[1])
+    out = ops.wgrad_wide(g, x)
+    assert calls == [(4, 128, (m - 3) // 4)]              # the split path ran
+    assert rel(out.cpu().numpy(), ref) < 5e-6              # (the single product: about 5e-6 as well)
+    assert rel(g.t().mm(x).cpu().numpy(), ref) < 2e-5
+    assert ops.wgrad_wide(g[:16000], x[:16000]).shape == (128, 192) and len(calls) == 1   # short batch: one product
+    big = torch.randn(m, 1024, device=dev)
+    ops.wgrad_wide(big, big)                               # 256 tiles: one product
+    assert len(calls) == 1
+    dims = (12, 192, 128, 64, 9)
+    lins = [torch.nn.Linear(a, b).to(dev) for a, b in zip(dims[:-1], dims[1:])]
+    params = [p for lin in lins for p in (lin.weight, lin.bias)]
+    xin, t = torch.randn(m, dims[0], device=dev), torch.randn(m, dims[-1], device=dev)
+    grads = {}
+    for split_rows in (16384, 1 << 40):
+        monkeypatch.setattr(ops, "WGRAD_SPLIT_ROWS", split_rows)
+        n0 = len(calls)
+        grads[split_rows] = torch.autograd.grad((ops.SpectralMLP.apply(xin, *params) * t).sum(), params)
+        assert (len(calls) > n0) == (split_rows == 16384)
+    for a, b in zip(grads[16384], grads[1 << 40]):
+        assert rel(a.cpu().numpy(), b.cpu().numpy()) < 2e-5
+
+
 def test_linear_act_first_layer_path(dev):
     """A Linear+ReLU layer on an input that needs no gradient takes the one-pass backward."""
     from sparc_amd.ops import LinearAct
