@@ -10,6 +10,16 @@ constexpr int ACT_RELU = 0;
 constexpr int ACT_TANH = 1;
 constexpr int COLSUM_LANES = 16;
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// 16 bytes that are read once: loaded past the caches' retention.  Used where whole 1024-column rows stream through
+// (the activation derivative: 117 -> 107 us); the narrow-layer kernels, whose workgroups touch 256-byte row segments,
+// lose with it (input gradient 49 -> 60 us), so they keep plain loads and stores.
+__device__ __forceinline__ float4 stream_load4(const float* p) {
+    const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+    return make_float4(t[0], t[1], t[2], t[3]);
+}
+
 template <int ACT>
 __device__ __forceinline__ float act_grad(float g, float h) {
     if (ACT == ACT_RELU) return h > 0.f ? g : 0.f;
@@ -38,14 +48,14 @@ __global__ __launch_bounds__(256) void act_bwd_bias_kernel(int64_t m, int n, con
 #pragma unroll 4
         for (int64_t r = r0 + ty; r < r1; r += rpi) {
             if constexpr (VEC == 4) {
-                const float4 gv = *reinterpret_cast<const float4*>(g + r * ldg + col);
-                const float4 hv = *reinterpret_cast<const float4*>(h + r * ldh + col);
+                const float4 gv = stream_load4(g + r * ldg + col);
+                const float4 hv = stream_load4(h + r * ldh + col);
                 float4 o;
                 o.x = act_grad<ACT>(gv.x, hv.x);
                 o.y = act_grad<ACT>(gv.y, hv.y);
                 o.z = act_grad<ACT>(gv.z, hv.z);
                 o.w = act_grad<ACT>(gv.w, hv.w);
-                *reinterpret_cast<float4*>(out + r * ldo + col) = o;
+                __builtin_nontemporal_store(v4f{o.x, o.y, o.z, o.w}, reinterpret_cast<v4f*>(out + r * ldo + col));
                 acc[0] += o.x;
                 acc[1 % VEC] += o.y;
                 acc[2 % VEC] += o.z;
@@ -121,7 +131,6 @@ ActPlan act_plan(int64_t m, int n, bool aligned) {
     return p;
 }
 
-typedef float v4f __attribute__((ext_vector_type(4)));
 
 // partial[chunk] = g[rows of chunk]^T h[rows of chunk][64-column block], f32 MFMA 16x16x4.
 // Lane l = (jj = l & 15, kk = l >> 4).  Per step of four rows the lane reads h[row kk][4 jj .. 4 jj + 3]
