@@ -429,6 +429,29 @@ def test_spectral_mlp_matches_torch_layers(dev, dims, x_grad):
         assert a.shape == b.shape and rel(a.cpu().numpy(), b.cpu().numpy()) < 1e-4
 
 
+def test_permutation_heads_from_the_host_travel_asynchronously_and_intact(dev):
+    """Host index lists reach the orthonormalisation through a ring of pinned staging buffers (no host stop inside
+    the forward pass): forty calls in a row without a synchronisation in between, more than twice round the ring,
+    give what the same heads give as device tensors; lists longer than a staging buffer take the blocking copy."""
+    from sparc_amd import ops
+    torch.manual_seed(2)
+    rng = np.random.default_rng(2)
+    m, k = 3000, 24
+    Y = torch.randn(m, k, device=dev)
+    heads = [rng.permutation(m)[:k] for _ in range(40)]
+    got = [ops.OrthWeights.apply(Y, h, 0) for h in heads]            # enqueued back to back
+    torch.cuda.synchronize()
+    for h, w in zip(heads, got):
+        ref = ops.OrthWeights.apply(Y, torch.as_tensor(h, device=dev, dtype=torch.int32), 0)
+        assert torch.equal(w, ref)
+    assert ops._index_staging[dev.index or 0].turn >= 40
+    long_list = rng.permutation(m)[:ops._IndexStaging.WIDTH + 5]
+    t = ops._index_to_device(long_list, dev)
+    assert t.dtype == torch.int32 and np.array_equal(t.cpu().numpy(), long_list)
+    assert ops._index_to_device(torch.arange(5, device=dev), dev).dtype == torch.int32
+    assert np.array_equal(ops._index_to_device(torch.arange(7), dev).cpu().numpy(), np.arange(7))   # a host tensor
+
+
 def test_weight_gradient_summed_in_parts(dev, monkeypatch):
     """Long batches sum the weight gradient of a wide layer whose result is small in four parts as one batched
     product (ops.wgrad_wide): against float64, with rows left over after the four parts, and through the whole
