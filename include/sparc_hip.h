@@ -214,7 +214,8 @@ int sparc_profile_end(double* total_ms, int64_t* launches);
  *                     summation order (bitwise reproducible).
  * sparc_orth_weights: mode 0 = reference (with S), 1 = S = I.  Wo float[k][k]; saved for the
  *                     backward: Rc, Rinv double[k][k], signs double[k]; *info (device int) is
- *                     set to j+1 if the Gram matrix is not positive definite at pivot j.
+ *                     set to j+1 if the Gram matrix is not positive definite at pivot j, to 0
+ *                     otherwise (always written: no need to clear it).
  * sparc_orth_apply:   Z = Yt Wo (transpose_w = 0) or Yt Wo^T (1): SpectralNetModel.forward's
  *                     last line (src/SpectralTrainer.py:103) and its backward wrt Yt.
  * sparc_orth_weights_bwd: given gWo = d loss / d Wo (double [k][k]) returns H = Gbar + Gbar^T

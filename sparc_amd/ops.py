@@ -367,7 +367,7 @@ class OrthWeights(torch.autograd.Function):
         Wo = torch.empty(k, k, dtype=torch.float32, device=dev)
         saved = torch.empty(2 * k * k + k, dtype=torch.float64, device=dev)
         Rc, Rinv, signs = saved[:k * k], saved[k * k:2 * k * k], saved[2 * k * k:]
-        info = torch.zeros(1, dtype=torch.int32, device=dev)
+        info = torch.empty(1, dtype=torch.int32, device=dev)   # written by every call
         tidx = None
         if top_idx is not None:
             tidx = _index_to_device(top_idx, dev)
