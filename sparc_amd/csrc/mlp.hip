@@ -359,6 +359,63 @@ __global__ __launch_bounds__(1024) void linear_narrow_fwd_kernel(int64_t m, int 
     }
 }
 
+// out = act(x W^T + b) for a narrow INPUT (K <= 16 columns) and a wide output: the MLP's first layer
+// (src/SpectralTrainer.py:28-39 on 10 node features).  The result is all the traffic (m x N floats against m x K
+// read), so the kernel is a store stream: a thread owns four consecutive output columns and keeps their 4 x K
+// weights in registers; the workgroup's NIN_ROWS rows of x wait in LDS (zero padded to KMAX columns), where every
+// lane reads the same address.  W is [N][K] row-major (torch's Linear.weight), K <= KMAX, N a multiple of 4.
+constexpr int NIN_ROWS = 32;
+
+template <int KMAX, int ACT>
+__global__ __launch_bounds__(256) void linear_narrow_in_fwd_kernel(int64_t m, int K, int N, const float* __restrict__ x,
+                                                                   int64_t ldx, const float* __restrict__ W,
+                                                                   const float* __restrict__ b, float* __restrict__ out,
+                                                                   int64_t ldo) {
+    __shared__ __attribute__((aligned(16))) float xs[NIN_ROWS * KMAX];
+    const int64_t r0 = (int64_t)blockIdx.x * NIN_ROWS;
+    const int rows = (int)min((int64_t)NIN_ROWS, m - r0);
+    for (int e = threadIdx.x; e < NIN_ROWS * KMAX; e += 256) {
+        const int r = e / KMAX, k = e - r * KMAX;
+        xs[e] = (r < rows && k < K) ? x[(r0 + r) * ldx + k] : 0.f;
+    }
+    const int c = (blockIdx.y * 256 + threadIdx.x) * 4;
+    const bool live = c < N;
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f w[2][KMAX], bias[2];    // column pairs (c, c + 1) and (c + 2, c + 3): packed fp32 multiply-adds
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        bias[t] = live ? v2f{b[c + 2 * t], b[c + 2 * t + 1]} : v2f{0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            w[t][k] = (live && k < K) ? v2f{W[(int64_t)(c + 2 * t) * K + k], W[(int64_t)(c + 2 * t + 1) * K + k]} : v2f{0.f, 0.f};
+    }
+    __syncthreads();
+    if (!live) return;
+    float* op = out + r0 * ldo + c;
+#pragma unroll 2
+    for (int r = 0; r < rows; ++r) {
+        v2f a[2] = {bias[0], bias[1]};
+#pragma unroll
+        for (int q = 0; q < KMAX / 4; ++q) {
+            const float4 xv = *reinterpret_cast<const float4*>(xs + r * KMAX + 4 * q);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = __builtin_elementwise_fma(v2f{xv.x, xv.x}, w[t][4 * q], a[t]);
+                a[t] = __builtin_elementwise_fma(v2f{xv.y, xv.y}, w[t][4 * q + 1], a[t]);
+                a[t] = __builtin_elementwise_fma(v2f{xv.z, xv.z}, w[t][4 * q + 2], a[t]);
+                a[t] = __builtin_elementwise_fma(v2f{xv.w, xv.w}, w[t][4 * q + 3], a[t]);
+            }
+        }
+        float o[4] = {a[0][0], a[0][1], a[1][0], a[1][1]};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (ACT == ACT_TANH) o[t] = tanhf(o[t]);
+            if (ACT == ACT_RELU) o[t] = fmaxf(o[t], 0.f);
+        }
+        *reinterpret_cast<float4*>(op + r * ldo) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 // dx = (g W) * [hprev > 0] and the column sums of dx, for a narrow g (n_out <= 64 columns): the input
 // gradient of the MLP's last layer fused with the ReLU derivative and the bias gradient of the layer
 // before it.  Workgroup = (64-column block of dx, chunk of rows); the block's slice of W lives in
@@ -609,6 +666,32 @@ extern "C" int sparc_linear_narrow_fwd(int64_t m, int K, int n_out, int act, con
     }
 #undef SPARC_FWD_ACT
 #undef SPARC_FWD
+    SPARC_CHECK_LAUNCH();
+    return SPARC_OK;
+}
+
+extern "C" int sparc_linear_narrow_in_fwd(int64_t m, int K, int N, int act, const float* x, int64_t ldx, const float* W,
+                                          const float* b, float* out, int64_t ldo, sparc_stream_t stream) {
+    if (m < 0 || K <= 0 || K > 16 || N <= 0 || N % 4 != 0 || (act != ACT_RELU && act != ACT_TANH && act != 2) || !x || !W || !b ||
+        !out || ldx < K || ldo < N || ldo % 4 != 0 || !aligned16(out))
+        return SPARC_ERR_ARG;
+    if (m == 0) return SPARC_OK;
+    const int ny = (N + 1023) / 1024;
+    dim3 grid((unsigned)((m + NIN_ROWS - 1) / NIN_ROWS), (unsigned)ny);
+#define SPARC_NIN(KM_, A_)                                                                                            \
+    hipLaunchKernelGGL((linear_narrow_in_fwd_kernel<KM_, A_>), grid, dim3(256), 0, stream, m, K, N, x, ldx, W, b, out, ldo)
+#define SPARC_NIN_ACT(KM_)                                  \
+    do {                                                    \
+        if (act == ACT_RELU) SPARC_NIN(KM_, ACT_RELU);      \
+        else if (act == ACT_TANH) SPARC_NIN(KM_, ACT_TANH); \
+        else SPARC_NIN(KM_, 2);                             \
+    } while (0)
+    if (K <= 4) SPARC_NIN_ACT(4);
+    else if (K <= 8) SPARC_NIN_ACT(8);
+    else if (K <= 12) SPARC_NIN_ACT(12);
+    else SPARC_NIN_ACT(16);
+#undef SPARC_NIN_ACT
+#undef SPARC_NIN
     SPARC_CHECK_LAUNCH();
     return SPARC_OK;
 }

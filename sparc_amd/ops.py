@@ -102,6 +102,21 @@ def linear_narrow_fwd(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, act: in
     return out
 
 
+def linear_narrow_in_fwd(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, act: int):
+    """act(x W^T + b) for a layer with at most 16 inputs (the first layer on a handful of node features): a store
+    stream with the weights in registers, or None when the shape does not fit it."""
+    m, K = x.shape
+    N = W.shape[0]
+    if (K > 16 or N % 4 or m == 0 or x.stride(1) != 1 or not W.is_contiguous() or not b.is_contiguous()
+            or x.dtype != torch.float32 or W.dtype != torch.float32 or b.dtype != torch.float32):
+        return None
+    out = torch.empty(m, N, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.sparc_linear_narrow_in_fwd(m, K, N, int(act), _ptr(x), x.stride(0), _ptr(W), _ptr(b), _ptr(out), N,
+                                             _stream()), "sparc_linear_narrow_in_fwd")
+    return out
+
+
 def dgrad_narrow_relu(g: torch.Tensor, W: torch.Tensor, hprev: torch.Tensor):
     """((g W) * [hprev > 0], its column sums): input gradient of a narrow layer fused with the ReLU
     derivative and bias gradient of the layer before it."""
@@ -142,7 +157,8 @@ class SpectralMLP(torch.autograd.Function):
         Ws, bs = params[0::2], params[1::2]
         acts = [x]
         for W, b in zip(Ws[:-1], bs[:-1]):
-            acts.append(torch._addmm_activation(b, acts[-1], W.t()))
+            h = linear_narrow_in_fwd(acts[-1], W, b, ACT_RELU) if len(acts) == 1 else None
+            acts.append(h if h is not None else torch._addmm_activation(b, acts[-1], W.t()))
         y = linear_narrow_fwd(acts[-1], Ws[-1], bs[-1], ACT_TANH)
         if y is None:
             y = torch.addmm(bs[-1], acts[-1], Ws[-1].t()).tanh_()
@@ -235,7 +251,10 @@ class LinearAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W, b, act):
         require_gpu(x.device)
-        if act == ACT_RELU:
+        h = linear_narrow_in_fwd(x, W, b, act) if x.dim() == 2 else None   # a handful of input columns
+        if h is not None:
+            pass
+        elif act == ACT_RELU:
             h = torch._addmm_activation(b, x, W.t())
         elif act == ACT_TANH:
             h = torch.addmm(b, x, W.t()).tanh_()

@@ -2,6 +2,8 @@
 reference-generated golden vectors.  Tolerances: bit-exact for index/degree work,
 1e-4 relative (float32) for embeddings, loss and gradients.
 """
+import ctypes
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -450,6 +452,32 @@ def test_permutation_heads_from_the_host_travel_asynchronously_and_intact(dev):
     assert t.dtype == torch.int32 and np.array_equal(t.cpu().numpy(), long_list)
     assert ops._index_to_device(torch.arange(5, device=dev), dev).dtype == torch.int32
     assert np.array_equal(ops._index_to_device(torch.arange(7), dev).cpu().numpy(), np.arange(7))   # a host tensor
+
+
+@pytest.mark.parametrize("m,K,N,act", [(1537, 10, 1024, 0), (1, 3, 4, 2), (5000, 16, 2052, 1), (333, 1, 64, 0),
+                                        (2049, 12, 512, 2), (40000, 10, 1024, 0)])
+def test_first_layer_forward_on_few_input_columns(dev, m, K, N, act):
+    """act(x W^T + b) for a layer with at most 16 inputs through its own kernel (a store stream with the weights
+    in registers) against torch in float64; rows of x may be longer than K (a view of a wider matrix)."""
+    from sparc_amd._lib import lib
+    from sparc_amd import ops
+    torch.manual_seed(m + K)
+    xw = torch.randn(m, K + 3, device=dev)
+    x = xw[:, :K]
+    lin = torch.nn.Linear(K, N).to(dev)
+    pre = x.double() @ lin.weight.double().t() + lin.bias.double()
+    ref = (torch.relu(pre) if act == 0 else torch.tanh(pre) if act == 1 else pre).detach().cpu().numpy()
+    out = ops.linear_narrow_in_fwd(x, lin.weight.detach(), lin.bias.detach(), act)
+    assert out is not None and out.shape == (m, N)
+    assert np.abs(out.cpu().numpy() - ref).max() < 2e-6 * max(1.0, np.abs(ref).max())
+    # the MLP's layers take it: same values as the library product to rounding, gradients as before
+    y = ops.LinearAct.apply(x, lin.weight, lin.bias, act)
+    assert torch.equal(y.detach(), out)
+    assert ops.linear_narrow_in_fwd(torch.randn(8, 17, device=dev), torch.randn(8, 17, device=dev), torch.randn(8, device=dev), 0) is None
+    assert ops.linear_narrow_in_fwd(torch.randn(8, 4, device=dev), torch.randn(6, 4, device=dev), torch.randn(6, device=dev), 0) is None
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    bad = lib.sparc_linear_narrow_in_fwd(m, 17, N, 0, P(x), x.stride(0), P(lin.weight), P(lin.bias), P(out), N, None)
+    assert bad == -1
 
 
 def test_weight_gradient_summed_in_parts(dev, monkeypatch):
