@@ -289,6 +289,10 @@ int sparc_first_layer_bwd(int64_t m, int din, int n, const float* x, int64_t ldx
                           const float* h, int64_t ldh, float* dWt_db, void* ws, size_t ws_bytes, sparc_stream_t stream);
 int sparc_linear_narrow_fwd(int64_t m, int K, int n_out, int act, const float* x, int64_t ldx, const float* W,
                             const float* b, float* out, int64_t ldo, sparc_stream_t stream);
+size_t sparc_dgrad_narrow_relu_workspace_bytes(int64_t m, int N);
+int sparc_dgrad_narrow_relu(int64_t m, int n_out, int N, const float* g, int64_t ldg, const float* W,
+                            const float* hprev, int64_t ldh, float* dx, int64_t ldx, float* db_prev,
+                            void* ws, size_t ws_bytes, sparc_stream_t stream);
 
 /* out = act(x W^T + b) for a narrow INPUT: x [m][K] with K <= 16 (the first layer of the MLP on a handful of node
  * features, src/SpectralTrainer.py:28-39), W [N][K] row-major, b [N], out [m][ldo] with N a multiple of 4 and out
@@ -296,10 +300,6 @@ int sparc_linear_narrow_fwd(int64_t m, int K, int n_out, int act, const float* x
  * store stream, the weights in registers. */
 int sparc_linear_narrow_in_fwd(int64_t m, int K, int N, int act, const float* x, int64_t ldx, const float* W,
                                const float* b, float* out, int64_t ldo, sparc_stream_t stream);
-size_t sparc_dgrad_narrow_relu_workspace_bytes(int64_t m, int N);
-int sparc_dgrad_narrow_relu(int64_t m, int n_out, int N, const float* g, int64_t ldg, const float* W,
-                            const float* hprev, int64_t ldh, float* dx, int64_t ldx, float* db_prev,
-                            void* ws, size_t ws_bytes, sparc_stream_t stream);
 
 /* ---- support / degree construction -----------------------------------------------------------
  * Replaces the sparse algebra of preprocess_multicluster / preprocess (src/utils.py:60-137):
