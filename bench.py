@@ -75,15 +75,17 @@ def cpu_baseline(graph, batches_nodes, bounds, shape, arch, sample_nodes, thread
 
 
 def inner_pass_bytes(b, k):
-    """(algorithmic, moved) bytes of ONE inner pass of the Laplacian chain on batch b at spectral dimension k:
-    the entry streams once, the row pointers, and three dense operands of width 2k (gathered operand,
-    own-row operand, result) -- at the real k for the algorithmic figure, at the kernel's column padding for
-    the bytes it actually moves."""
-    entry = b.nnz * (4 + 4 + (4 if b.valT is not None else 0)) + (b.m + 1) * 8
+    """(algorithmic, moved, algorithmic with mirrored values) bytes of ONE inner pass of the Laplacian chain on batch b
+    at spectral dimension k.  Algorithmic: every stored entry once as index + value (8 bytes), the row pointers, and
+    three dense operands of width 2k (gathered operand, own-row operand, result) at the real k.  Moved: what the
+    kernel that runs actually reads and writes (its column padding, its own entry format).  The third figure counts
+    4 more bytes per entry for supports whose mirrored values differ (A[j][i] stored beside A[i][j])."""
+    entry = b.nnz * (4 + 4) + (b.m + 1) * 8
+    mirrored = b.nnz * 4 if b.valT is not None else 0
     path = b.pass_kernel(k, True)
     t = b.tiling(k, True) if path == "tiles" else None
     kp = t.kp if t is not None else (16 if k <= 16 else 32 if k <= 32 else 64)
-    moved = entry + 3 * b.m * 2 * kp * 4
+    moved = entry + mirrored + 3 * b.m * 2 * kp * 4
     if t is not None and getattr(t, "pattern", False):   # row-factor form: addresses only, plus 16 bytes of row factors per row
         moved = b.nnz * 4 + (b.m + 1) * 8 + b.m * 16 + 3 * b.m * 2 * kp * 4
     if path == "blocks":   # the blocks as dense arrays, the other entries as CSR, and the intermediate result written and re-read
@@ -91,20 +93,25 @@ def inner_pass_bytes(b, k):
         per = 4 + 4 + (4 if b.valT is not None else 0)
         n_blk = sum(int(d[2]) * 32 for d in bl["keep"][0].cpu().numpy()) * (2 if b.valT is not None else 1)
         moved = n_blk * 4 + bl["r_nnz"] * per + (b.m + 1) * 8 + 5 * b.m * 2 * kp * 4
-    return entry + 3 * b.m * 2 * k * 4, moved
+    dense = 3 * b.m * 2 * k * 4
+    return entry + dense, moved, entry + mirrored + dense
 
 
 def recorded_traffic(workload, b, k):
-    """HBM bytes per launch of the inner pass from the rocprofv3 counter passes (tools/run_pmc.sh,
-    tools/collect_traffic.py) -- only if they were taken on this workload's batch shape; else None."""
+    """(HBM bytes per launch of the inner pass, where that figure was recorded) from the rocprofv3 counter passes
+    (tools/run_pmc.sh, tools/collect_traffic.py): a recorded figure, not a measurement of this run, and only given
+    if it was taken on this workload's batch shape; else (None, None)."""
     path = os.path.join(ROOT, "profiles", "spmm_hbm_traffic.json")
     try:
         rec = json.load(open(path))
     except Exception:
-        return None
+        return None, None
     same = rec.get("workload") == workload and rec.get("k") == k and abs(rec.get("m", 0) - b.m) <= 0.05 * b.m and \
         abs(rec.get("nnz", 0) - b.nnz) <= 0.05 * b.nnz
-    return rec.get("bytes_per_launch") if same else None
+    if not same:
+        return None, None
+    return rec.get("bytes_per_launch"), (f"profiles/spmm_hbm_traffic.json: rocprofv3 --pmc passes over an inner pass on a {rec.get('workload')}-shape "
+                                         f"batch of {rec.get('m')} rows, {rec.get('nnz')} entries, k = {rec.get('k')} (not this run)")
 
 
 def side_measurements(trainer, lib, check, k, dev, reps=30):
@@ -124,7 +131,7 @@ def side_measurements(trainer, lib, check, k, dev, reps=30):
     tot, n = ctypes.c_double(0.0), ctypes.c_int64(0)
     check(lib.sparc_profile_end(ctypes.byref(tot), ctypes.byref(n)), "sparc_profile_end")
     lap_us = tot.value / max(n.value, 1) * 1e3
-    alg, _ = inner_pass_bytes(b, k)
+    alg, _, _ = inner_pass_bytes(b, k)
     lap_alg = alg - b.m * 2 * k * 4 + b.m * k * 4 + b.m * 32     # writes the gradient [m][k] instead of [m][2k]; reads the row records
     for _ in range(3):
         gram(Y, Y)
@@ -147,6 +154,47 @@ def side_measurements(trainer, lib, check, k, dev, reps=30):
     }
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes through
+    torch.distributed.run (one per GPU, rendezvous on 127.0.0.1) with this command line, let them print to this
+    process's stdout / stderr, and return their exit status.  Must run before anything initialises the GPU here."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs between the ranks on these hosts
+    print(f"[bench] starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def check_launch(world: int, rank: int, local_rank: int, backend: str) -> None:
+    """--check-launch: the ranks meet, sum their rank numbers and rank 0 reports what it saw; no kernel runs.  On a
+    host without a GPU the group is formed over gloo."""
+    has_gpu = torch.cuda.is_available()
+    if not has_gpu:
+        backend = "gloo"
+    dev = torch.device("cuda", int(os.environ.get("SPARC_BENCH_DEVICE", local_rank))) if has_gpu else torch.device("cpu")
+    total = torch.tensor([float(rank)], device=dev if backend == "nccl" else "cpu")
+    if world > 1:
+        if has_gpu:
+            torch.cuda.set_device(dev)
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+        dist.all_reduce(total)
+        seen = dist.get_world_size()
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        seen = 1
+    if rank == 0:
+        print(json.dumps({"launch_check": {"world": seen, "env_world": world, "backend": backend if world > 1 else None,
+                                           "rank_sum": float(total[0]), "device": str(dev)}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,15 +207,27 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=16384)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hip-graph", action="store_true", help="replay whole steps as HIP graphs (one GPU; small batches)")
+    ap.add_argument("--kernel-choice", choices=["rule", "measure"], default="rule",
+                    help="rule: a batch's kernel follows from its structure (runs repeat bit for bit, ranks agree); "
+                         "measure: time the candidates on every batch and keep the fastest")
+    ap.add_argument("--check-launch", action="store_true",
+                    help="only start the ranks, form the process group, all-reduce one number and report the world")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))     # nothing has touched the GPU in this process
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU path)")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start the ranks with torch.distributed.run "
+                         f"--nproc-per-node {args.gpus}, or leave WORLD_SIZE unset and bench.py starts them itself")
     # rehearsal knobs for a one-GPU box: several ranks on one card over gloo (never used by the driver)
     backend = os.environ.get("SPARC_BENCH_BACKEND", "nccl")
+    if args.check_launch:
+        return check_launch(world, rank, local_rank, backend)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path)")
     if "SPARC_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["SPARC_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
@@ -177,7 +237,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        print(f"[bench] rank {dist.get_rank()} of {dist.get_world_size()} ({dist.get_backend()}): {dev}, "
+              f"{torch.cuda.get_device_name(dev)}", file=sys.stderr, flush=True)
 
     from sparc_amd import synth
     from sparc_amd._lib import lib, check
@@ -205,7 +266,7 @@ def main():
         pt = nodes_of[b]
         coords, values, shp, _ = graph.subblock(pt, mode=(0 if lam == -1 else 2), binarize=False, diag_lambda=lam)
         csz = np.diff(bounds.cpu().numpy())[cluster_ids[b]]
-        cb = ClusterBatch.from_device_coo(shp[0], coords, values, cluster_sizes=csz).warm(k, measure=True)
+        cb = ClusterBatch.from_device_coo(shp[0], coords, values, cluster_sizes=csz).warm(k, measure=args.kernel_choice == "measure")
         trainer.add_batch(synth.block_features(pt, bounds, din, 47), cb)
     torch.cuda.synchronize()
     t_prep = time.perf_counter() - t0
@@ -234,15 +295,16 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     nodes = 0
-    alg_bytes = moved_bytes = 0.0
+    alg_bytes = moved_bytes = alg12_bytes = 0.0
     losses = []
     for s in range(args.warmup, args.warmup + args.steps):
         pid, loss = one_step(s)
         nodes += ms[pid]
         b = trainer.batches[pid]
-        a_b, m_b = inner_pass_bytes(b, k)
+        a_b, m_b, a12_b = inner_pass_bytes(b, k)
         alg_bytes += 2 * a_b
         moved_bytes += 2 * m_b
+        alg12_bytes += 2 * a12_b
         losses.append(loss)
     t_host = time.perf_counter() - t0     # the host's share: how long it took to enqueue the steps
     torch.cuda.synchronize()
@@ -283,6 +345,7 @@ def main():
         path = b0.pass_kernel(k, True)
         t0_ = b0.tiling(k, True) if path == "tiles" else None
         row_factor_form = bool(t0_ is not None and getattr(t0_, "pattern", False))
+        traffic, traffic_src = recorded_traffic(args.workload, b0, k)
         kernel = (f"spmm_win<vec {t0_.vec}, dual, add-x0{', row-factor form' if row_factor_form else ''}> (kp {t0_.kp})" if path == "tiles" else
                   "dense_blocks<add-x0> (matrix cores, the clusters' diagonal blocks) + spmm_rows<dual, add-x0> on the other entries (kp 64)"
                   if path == "blocks" else f"spmm_rows<dual, add-x0> (kp {16 if k <= 16 else 32 if k <= 32 else 64})") + \
@@ -301,11 +364,12 @@ def main():
                        "mean_loss": final_loss},
             "roofline": {"bound": "hbm", "kernel": kernel,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": recorded_traffic(args.workload, b0, k), "avg_kernel_us": kern_ms * 1e3,
+                         "traffic": traffic, "traffic_recorded_on": traffic_src, "avg_kernel_us": kern_ms * 1e3,
                          "launches_timed": int(launches.value),
                          "algorithmic_bytes_per_launch": per_launch,
-                         "algorithmic_bytes_formula": "nnz*(4+4[+4 mirrored values]) + 8*(m+1) + 3*m*(2k)*4 (gathered operand, "
-                                                      "own-row operand, result; width 2k = [A half | A^T half])",
+                         "algorithmic_bytes_formula": "nnz*(4+4) + 8*(m+1) + 3*m*(2k)*4 (gathered operand, own-row operand, "
+                                                      "result; width 2k = [A half | A^T half])",
+                         "algorithmic_bytes_per_launch_with_mirrored_values": alg12_bytes / max(2 * args.steps, 1),
                          "bytes_moved_per_launch": moved_bytes / max(2 * args.steps, 1),
                          "note": ("row-factor form of the support: the value streams that the algorithmic bytes count are "
                                   "not read, so measured traffic lies below them") if row_factor_form else None},

@@ -47,6 +47,10 @@ typedef struct ihipStream_t* sparc_stream_t; /* == hipStream_t */
 #define SPARC_ROWC 8 /* {+-1/rho, S_ii, d + cw, 1/sqrt(d), r, r2, c, c2}; 1/rho < 0 flags an isolated row */
 
 int sparc_abi_version(void);
+/* Per-device set-up, to be called once with the device current before its first use from code that may not query
+ * the runtime later (HIP graph capture): looks up the device addresses of the arrays that are part of the library
+ * image (the scratch of sparc_gram_static).  No counterpart in the reference.  Calling it again is free. */
+int sparc_init(void);
 
 /* ---- support matrix: COO tuple -> dual-value CSR -----------------------------------
  * Replaces SpectralTrainer._get_support_matrix (src/SpectralTrainer.py:275-281): the
@@ -229,8 +233,10 @@ int sparc_gram(int64_t m, int k, const float* A, int64_t lda, const float* B, in
  * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  Same kernels,
  * same fixed summation order and bitwise the same G as sparc_gram; the partial Gram matrices go
  * to a 4 MiB array that is part of the library image on every GPU (128 blocks x 64 x 64 doubles),
- * which covers every m and every k <= SPARC_MAX_K; anything beyond returns SPARC_ERR_SIZE.  The
- * first call on a device looks the array's address up (with that device current); no call
+ * which covers every m and every k <= SPARC_MAX_K; anything beyond returns SPARC_ERR_SIZE.
+ * sparc_init() looks the array's address up on the current device; call it once per device before
+ * the first sparc_gram_static that runs under stream capture (without it the first call on a
+ * device does the look-up itself, a runtime query that does not belong inside a capture).  No call
  * allocates.  All calls on one GPU share the array: calls that overlap on one GPU (different
  * streams or threads) race. */
 int sparc_gram_static(int64_t m, int k, const float* A, int64_t lda, const float* B, int64_t ldb,

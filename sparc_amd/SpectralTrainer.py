@@ -37,6 +37,7 @@ class SpectralNetModel(nn.Module):
         self.device = device
         self.orthonorm_weights = torch.eye(self.input_dim).to(self.device)  # as the reference (:24)
         self.rotation_matrix = None
+        self.grad_ready_hook = None   # hook(layer, dW, db) -> (dW, db), called during the backward (ops._layer_done)
         self.orth_mode = {"reference": ORTH_REFERENCE, "cholesky": ORTH_CHOLESKY}[orth_mode]
 
         current_dim = self.input_dim
@@ -58,7 +59,7 @@ class SpectralNetModel(nn.Module):
         kinds = [isinstance(layer[1], nn.Tanh) for layer in self.layers]
         if kinds[-1] and not any(kinds[:-1]) and x.dtype == torch.float32:   # ReLU ... ReLU, Tanh: the fused MLP
             params = [p for layer in self.layers for p in (layer[0].weight, layer[0].bias)]
-            return SpectralMLP.apply(x.contiguous(), *params)
+            return SpectralMLP.apply(x.contiguous(), self.grad_ready_hook, *params)
         for layer, is_tanh in zip(self.layers, kinds):
             x = LinearAct.apply(x, layer[0].weight, layer[0].bias, ACT_TANH if is_tanh else ACT_RELU)
         return x
@@ -85,14 +86,31 @@ class SpectralNetModel(nn.Module):
 class SpectralNetLoss(nn.Module):
     """Rayleigh quotient of the batch Laplacian (src/SpectralTrainer.py:111-139).
 
-    W is the ClusterBatch returned by SpectralTrainer._get_valid_affinity_matrix (the
-    reference passes the dense m x m matrix it describes).
+    W is the ClusterBatch returned by SpectralTrainer._get_valid_affinity_matrix, or the dense
+    m x m affinity itself, as the reference passes it (:116): a dense matrix has no sparsity for
+    the kernels to use, so it takes the same quadratic form with one library product.
     """
 
     def forward(self, W, Y: torch.Tensor, is_normalized: bool = False) -> torch.Tensor:
-        if not isinstance(W, ClusterBatch):
-            raise TypeError("W must be a sparc_amd.graph.ClusterBatch (build one with ClusterBatch.from_support)")
-        return LapLoss.apply(Y, W, bool(is_normalized))
+        if isinstance(W, ClusterBatch):
+            return LapLoss.apply(Y, W, bool(is_normalized))
+        if torch.is_tensor(W) and W.dim() == 2 and W.shape[0] == W.shape[1] == Y.shape[0] and W.is_floating_point():
+            return self._dense(W, Y, bool(is_normalized))
+        raise TypeError("W must be a sparc_amd.graph.ClusterBatch (build one with ClusterBatch.from_support) or the "
+                        "dense m x m affinity matrix of the batch")
+
+    @staticmethod
+    def _dense(W: torch.Tensor, Y: torch.Tensor, is_normalized: bool) -> torch.Tensor:
+        """sum_ij W_ij |y_i - y_j|^2 / (2 m)  =  [ 1/2 sum_i (d_i + c_i) |y_i|^2 - sum_i y_i . (W y)_i ] / m  with the row
+        sums d and column sums c of W (src/SpectralTrainer.py:130-137, where it is written with torch.cdist)."""
+        require_gpu(W.device)
+        m = Y.shape[0]
+        W = W.detach().to(Y.dtype)
+        d = W.sum(dim=1)
+        if is_normalized:
+            Y = Y / torch.sqrt(d[:, None])
+        half = 0.5 * (d + W.sum(dim=0))
+        return (Y * (half[:, None] * Y - W @ Y)).sum() / m    # tr(Y^T L Y) / m, L = 1/2 (D_r + D_c) - W
 
 
 class SpectralTrainer:
@@ -109,6 +127,7 @@ class SpectralTrainer:
         self.architecture = self.spectral_config["architecture"]
         self.n_clusters = self.spectral_config["n_clusters"]
         self.weights_path = f"./weights/{self.dataset}/spectralnet_weights.pth"
+        self.orth_weights_path = f"./weights/{self.dataset}/spectralnet_orthonorm_weights.pth"
         self.orth_mode = self.spectral_config.get("orth_mode", "reference")
         self._batches = {}
 
@@ -135,50 +154,123 @@ class SpectralTrainer:
         except Exception:
             return None
 
-    def _get_valid_affinity_matrix(self, W: ClusterBatch, X=None) -> ClusterBatch:
-        return W  # the affinity vectors were prepared together with the CSR
+    def _get_valid_affinity_matrix(self, W, X=None):
+        """A ClusterBatch comes back as it is: its affinity vectors were prepared together with the CSR.  A dense
+        support matrix (what the reference's _get_support_matrix returns) is taken through the reference's own
+        dense sequence (src/SpectralTrainer.py:288-291) with library products; SpectralNetLoss accepts the result."""
+        if torch.is_tensor(W):
+            require_gpu(W.device)
+            W0 = W + 1e-6
+            W2 = W0 @ W0
+            Wp = W0 + W2 + W2 @ W0
+            Wp.fill_diagonal_(0)
+            return torch.nn.functional.normalize(Wp, p=2, dim=1)
+        return W
+
+    # -- set-up steps of train(), separate so that the epoch loop can be driven on stand-ins ---
+    def _setup_model(self, input_dim: int):
+        self.criterion = SpectralNetLoss()
+        self.spectral_net = SpectralNetModel(self.architecture, input_dim=input_dim, device=self.device,
+                                             orth_mode=self.orth_mode).to(self.device)
+
+    def _setup_optimizer(self, hip_graph: bool):
+        self._lr_tensor = None
+        if hip_graph:   # the graphs read the learning rate from a device tensor
+            self._lr_tensor = torch.tensor(float(self.lr), device=self.device)
+            self.optimizer = optim.Adam(self.spectral_net.parameters(), lr=self._lr_tensor, fused=True, capturable=True)
+        else:
+            fused = torch.device(self.device).type == "cuda"
+            self.optimizer = optim.Adam(self.spectral_net.parameters(), lr=self.lr, fused=fused)  # one launch per step
+        self.scheduler = optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, mode="min", factor=self.lr_decay,
+                                                              patience=self.patience)
+
+    def _prepare_batches(self, k: int, mine, mine_val):
+        """One-time: this rank's features and supports to the device (train batches `mine`, validation batches
+        `mine_val`, both lists of indices into the tuples train() received)."""
+        measure = self.spectral_config.get("kernel_choice", "rule") == "measure"
+        sizes = self._cluster_sizes()
+        feats = [self.features_batches[b].to(self.device, dtype=torch.float32) for b in mine]
+        sup = [self._get_support_matrix(self.support_batches[b], sizes[b] if sizes else None).warm(k, measure=measure)
+               for b in mine]
+        vfeats = [self.val_features_batches[b].to(self.device, dtype=torch.float32) for b in mine_val]
+        vsup = [self._get_support_matrix(self.val_support_batches[b]).warm(k, training=False, measure=measure)
+                for b in mine_val]
+        return feats, sup, vfeats, vsup
 
     def train(self, train, val) -> SpectralNetModel:
+        """The reference's loop (src/SpectralTrainer.py:170-272).  Inside an initialised torch.distributed process
+        group of more than one rank (one process per GPU) the loop is data-parallel: the training and validation
+        batches are dealt round-robin to the ranks (each rank prepares and keeps only its own), every rank takes the
+        same number of steps per epoch on its own batches, the MLP gradient is averaged over the ranks layer by
+        layer during the backward (the only collective of a step), the epoch's loss sums and the validation loss are
+        summed over the ranks before the scheduler sees them, and rank 0 alone prints and writes the checkpoint.
+        Without a process group (or with one rank) it is the reference's sequential loop, draw for draw.
+
+        Config keys beyond the reference's, all optional: spectral.orth_mode ("reference" | "cholesky"),
+        spectral.hip_graph (whole steps replayed as HIP graphs; one GPU), spectral.kernel_choice ("rule": the kernel
+        of a batch follows from its structure, so runs repeat bit for bit; "measure": the candidates are timed on
+        the batch and the fastest kept)."""
         require_gpu(self.device)
         self.parts, self.features_batches, self.support_batches, self.y_train_batches, self.train_mask_batches = train
         self.idx_parts, self.val_features_batches, self.val_support_batches, self.y_val_batches, self.val_mask_batches = val
         self.idx_parts = list(range(len(self.parts)))
         self.counter = 0
         OrthWeights.check_and_reset(self.device)   # failures of earlier, unrelated calls do not belong to this run
-        self.criterion = SpectralNetLoss()
-        self.spectral_net = SpectralNetModel(self.architecture, input_dim=self.features_batches[0].shape[1],
-                                             device=self.device, orth_mode=self.orth_mode).to(self.device)
+        self._setup_model(self.features_batches[0].shape[1])
+        world, rank = self._world()
         # spectral.hip_graph (not a reference key; default off): whole steps replayed as HIP graphs, one launch per step
-        hip_graph = bool(self.spectral_config.get("hip_graph", False))
-        if hip_graph:
-            lr_t = torch.tensor(float(self.lr), device=self.device)
-            self.optimizer = optim.Adam(self.spectral_net.parameters(), lr=lr_t, fused=True, capturable=True)
-        else:
-            self.optimizer = optim.Adam(self.spectral_net.parameters(), lr=self.lr, fused=True)  # one launch per step
-        self.scheduler = optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, mode="min", factor=self.lr_decay,
-                                                              patience=self.patience)
+        hip_graph = bool(self.spectral_config.get("hip_graph", False)) and world == 1
+        self._setup_optimizer(hip_graph)
         k = self.architecture["output_dim"]
-
-        # one-time: features and supports to the device
-        feats = [f.to(self.device, dtype=torch.float32) for f in self.features_batches]
-        sizes = self._cluster_sizes()
-        sup = [self._get_support_matrix(s, sizes[i] if sizes else None).warm(k, measure=True)
-               for i, s in enumerate(self.support_batches)]
-        vfeats = [f.to(self.device, dtype=torch.float32) for f in self.val_features_batches]
-        vsup = [self._get_support_matrix(s).warm(k, training=False, measure=True) for s in self.val_support_batches]
-
+        mine, mine_val = self._my_share(len(self.features_batches), len(self.val_features_batches), world, rank)
+        feats, sup, vfeats, vsup = self._prepare_batches(k, mine, mine_val)
         graphed = None
         if hip_graph:
             from .stepgraph import GraphedSteps
             graphed = GraphedSteps(self.spectral_net, self.criterion, self.optimizer, feats, sup, k, self.device)
+        return self._run_epochs(feats, sup, vfeats, vsup, k, graphed, n_val_total=len(self.val_features_batches))
 
+    @staticmethod
+    def _world():
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(), dist.get_rank()
+        return 1, 0
+
+    @staticmethod
+    def _my_share(n_train: int, n_val: int, world: int, rank: int):
+        """Indices of the training and validation batches this rank owns (round-robin).  A rank that would be left
+        without a training batch (more ranks than batches) trains on one of the others' so that every rank takes
+        part in every collective; validation batches are never doubled (their losses are summed over the ranks)."""
+        from .parallel import shard_batches
+        mine = shard_batches(n_train, world, rank) or [rank % max(n_train, 1)]
+        return mine, shard_batches(n_val, world, rank)
+
+    def _run_epochs(self, feats, sup, vfeats, vsup, k: int, graphed=None, n_val_total=None):
+        world, rank = self._world()
+        reducer = None
+        if world > 1:
+            from .parallel import LayerwiseReducer, all_reduce_sum, broadcast
+            params = list(self.spectral_net.parameters())
+            for p in params:                      # every replica starts from rank 0's weights
+                broadcast(p.data, 0)
+            reducer = LayerwiseReducer(params)
+            self.spectral_net.grad_ready_hook = reducer.on_layer
         min_val_loss = 1000000000
         batches = len(feats)
-        batches_val = len(vfeats)
-        print("Training SpectralNet:")
+        batches_val = len(vfeats) if n_val_total is None else n_val_total
+        steps = batches
+        if world > 1:                             # the ranks take the same number of steps: the largest share's
+            t = torch.tensor([batches], dtype=torch.int64)
+            t = t.to(self.device) if torch.distributed.get_backend() == "nccl" else t
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            steps = int(t)
+        if rank == 0:
+            print("Training SpectralNet:")
         for epoch in range(self.epochs):
             train_loss = torch.zeros((), dtype=torch.float64, device=self.device)
-            for pid in range(batches):
+            for step in range(steps):
+                pid = step % batches
                 pid_2 = np.random.choice(batches)
                 np.random.permutation(len(feats[pid]))           # drawn as the reference does (:211), not applied
                 perm_2 = np.random.permutation(len(feats[pid_2]))  # (:218) only its head matters
@@ -189,21 +281,34 @@ class SpectralTrainer:
                     train_loss += graphed.step(pid, pid_2, perm_2[:k])
                     continue
                 self.spectral_net.train()
-                self.optimizer.zero_grad()
+                self.optimizer.zero_grad(set_to_none=True)
                 Y = self.spectral_net.forward_pair(feats[pid_2], feats[pid], top_idx=perm_2[:k])
                 W = self._get_valid_affinity_matrix(sup[pid], feats[pid])
                 loss = self.criterion(W, Y, is_normalized=True)
                 loss.backward()
+                if reducer is not None and reducer.finish() == 0:
+                    from .parallel import all_reduce_mean_gradients
+                    all_reduce_mean_gradients(list(self.spectral_net.parameters()))
                 self.optimizer.step()
                 train_loss += loss.detach()
 
             valid_loss = torch.zeros((), dtype=torch.float64, device=self.device)
             self.spectral_net.eval()
             with torch.no_grad():
-                for pid in range(batches_val):
+                for pid in range(len(vfeats)):
                     Y = self.spectral_net(vfeats[pid], should_update_orth_weights=False)
                     W = self._get_valid_affinity_matrix(vsup[pid], vfeats[pid])
                     valid_loss += self.criterion(W, Y, is_normalized=True)
+            failed = OrthWeights.worst_info.get(torch.device(self.device).index or 0)
+            n_steps = steps
+            if world > 1:     # one small collective per epoch: both loss sums and the failure flag of every rank
+                packed = torch.stack([train_loss, valid_loss, (failed.double().reshape(()) if failed is not None
+                                                                else torch.zeros_like(train_loss))])
+                all_reduce_sum(packed)
+                train_loss, valid_loss = packed[0], packed[1]
+                if failed is not None:
+                    failed.fill_(int(packed[2] != 0))
+                n_steps = steps * world
             train_loss, valid_loss = float(train_loss), float(valid_loss)  # the epoch's only host sync
             if OrthWeights.check_and_reset(self.device) != 0:   # any step of the epoch, not only the last
                 raise torch.linalg.LinAlgError("orthonormalisation: the batch's Gram matrix is not positive definite "
@@ -211,20 +316,37 @@ class SpectralTrainer:
 
             self.scheduler.step(valid_loss)
             current_lr = float(self.optimizer.param_groups[0]["lr"])
-            if hip_graph and self.optimizer.param_groups[0]["lr"] is not lr_t:   # the graphs read the rate from lr_t
+            lr_t = self._lr_tensor
+            if lr_t is not None and self.optimizer.param_groups[0]["lr"] is not lr_t:   # the graphs read the rate from lr_t
                 lr_t.fill_(current_lr)
                 self.optimizer.param_groups[0]["lr"] = lr_t
             if current_lr <= self.spectral_config["min_lr"]:
                 break
-            print(f"Epoch: {epoch + 1}/{self.epochs}, Train Loss: {train_loss / batches:.7f}, "
-                  f"Valid Loss: {valid_loss / batches_val:.7f}, LR: {current_lr:.6f}")
+            if rank == 0:
+                print(f"Epoch: {epoch + 1}/{self.epochs}, Train Loss: {train_loss / n_steps:.7f}, "
+                      f"Valid Loss: {valid_loss / batches_val:.7f}, LR: {current_lr:.6f}")
 
             if valid_loss <= min_val_loss:
                 min_val_loss = valid_loss
-                self.save_model()
+                if rank == 0:
+                    self.save_model()
 
         return self.spectral_net
 
     def save_model(self):
+        """The reference's checkpoint (state_dict of the MLP, src/SpectralTrainer.py:339-343) and, in a file next to
+        it, the orthonormalisation weights of the last training step: they are an attribute of the reference's module,
+        not a registered buffer (:24), so a reloaded state_dict alone cannot predict."""
         os.makedirs(os.path.dirname(self.weights_path), exist_ok=True)  # the reference never creates weights/<dataset>/
         torch.save(self.spectral_net.state_dict(), self.weights_path)
+        torch.save({"orthonorm_weights": self.spectral_net.orthonorm_weights.detach().cpu()}, self.orth_weights_path)
+
+    def load_model(self, input_dim: int) -> SpectralNetModel:
+        """A SpectralNetModel with the checkpoint's MLP weights and, when the file next to it exists, the
+        orthonormalisation weights that were current when the checkpoint was written."""
+        self._setup_model(input_dim)
+        self.spectral_net.load_state_dict(torch.load(self.weights_path, map_location=self.device, weights_only=True))
+        if os.path.exists(self.orth_weights_path):
+            extra = torch.load(self.orth_weights_path, map_location=self.device, weights_only=True)
+            self.spectral_net.orthonorm_weights = extra["orthonorm_weights"].to(self.device)
+        return self.spectral_net

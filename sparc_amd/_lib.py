@@ -44,6 +44,7 @@ lib = _load()
 P = c_void_p
 _SIGS = {
     "sparc_abi_version": (c_int, []),
+    "sparc_init": (c_int, []),
     "sparc_csr_build_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "sparc_csr_build": (c_int, [c_int64, c_int64, P, P, P, P, P, P, P, P, P, c_size_t, P]),
     "sparc_affinity_prep_workspace_bytes": (c_size_t, [c_int64, c_int64]),
@@ -85,6 +86,19 @@ for _name, (_res, _args) in _SIGS.items():
     _fn.argtypes = _args
 
 EXPORTS = tuple(_SIGS)
+
+
+_initialised = set()
+
+
+def init_device(index: int) -> None:
+    """sparc_init() once per device, with that device current."""
+    if index in _initialised:
+        return
+    import torch
+    with torch.cuda.device(index):
+        check(lib.sparc_init(), "sparc_init")
+    _initialised.add(index)
 
 
 def check(rc, what):

@@ -167,10 +167,15 @@ __global__ __launch_bounds__(FUSED ? 1024 : 256) void dense_blocks(const BlocksA
         __syncthreads();
     } else if (wave < 4) {
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the zero fill
-        if (lane == 0) atomicAdd(&staged, 1);
-        // (bounded, so that the grid drains whatever happens: the four waves always arrive, within microseconds)
-        for (int spin = 0; spin < (1 << 20) && __atomic_load_n(&staged, __ATOMIC_RELAXED) < 4; ++spin) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // release / acquire on the counter: a wave that sees four arrivals also sees what the four staged
+        if (lane == 0) __hip_atomic_fetch_add(&staged, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // bounded, so that the grid drains whatever happens (the four waves always arrive, within microseconds);
+        // a wave that gave up must not multiply operands that were never staged: it stops the kernel instead
+        int spin = 0;
+        while (__hip_atomic_load(&staged, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 4) {
+            if (++spin > (1 << 20)) __builtin_trap();
+            __builtin_amdgcn_s_sleep(1);
+        }
     }
 
     if (FUSED && wave >= 4) {   // rows of the stripe, dealt to the twelve gather waves

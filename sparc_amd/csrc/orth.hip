@@ -568,7 +568,7 @@ std::mutex g_scratch_mutex;
 void* g_scratch_ptr[MAX_DEVICES] = {};  // device address of `scratch` on each device, looked up once
 
 // The address of `scratch` on the current device (nullptr on failure).  The first call on a device asks
-// the runtime for it; later calls only read the table.
+// the runtime for it (sparc_init does, so that no later call has to); later calls only read the table.
 void* scratch_on_current_device() {
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return nullptr;
@@ -581,6 +581,10 @@ void* scratch_on_current_device() {
     return g_scratch_ptr[dev];
 }
 }  // namespace
+
+extern "C" int sparc_init(void) {
+    return scratch_on_current_device() ? SPARC_OK : SPARC_ERR_LAUNCH;
+}
 
 extern "C" int sparc_gram(int64_t m, int k, const float* A, int64_t lda, const float* B, int64_t ldb, double* G,
                           void* ws, size_t ws_bytes, sparc_stream_t stream) {

@@ -184,6 +184,7 @@ def require_gpu(device):
     if device.type != "cuda":
         raise _lib.SparcHipError("sparc_amd runs on an MI355X only (device must be a ROCm 'cuda' device); "
                                  "there is no CPU path")
+    _lib.init_device(device.index if device.index is not None else torch.cuda.current_device())
     return device
 
 
@@ -551,7 +552,9 @@ class ClusterBatch:
         names = [n for n, ok in (("blocks", self.blocks(k, training) is not None), ("tiles", self.tiling(k, training) is not None),
                                  ("rows", True)) if ok]
         if len(names) > 1 and measure and (k, bool(training)) not in self._measured:
-            Y = torch.randn(self.m, k, device=self.device)
+            gen = torch.Generator(device=self.device)       # a private stream of numbers: the caller's stays where it was
+            gen.manual_seed(0)
+            Y = torch.randn(self.m, k, device=self.device, generator=gen)
             took = {}
             for name in names:
                 self._measured[(k, bool(training))] = name

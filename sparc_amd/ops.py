@@ -132,15 +132,12 @@ def dgrad_narrow_relu(g: torch.Tensor, W: torch.Tensor, hprev: torch.Tensor):
     return dx, db
 
 
-# Called by SpectralMLP.backward as soon as a layer's weight and bias gradient exist: hook(layer, dW, db) returns the
-# pair to hand to autograd (a data-parallel trainer returns views into a bucket whose all-reduce it has just
-# started, so the collective overlaps the backward products of the layers below).  None: no hook.
-GRAD_READY_HOOK = None
-
-
-def _layer_done(grads, l):
-    if GRAD_READY_HOOK is not None and grads[2 * l] is not None and grads[2 * l + 1] is not None:
-        grads[2 * l], grads[2 * l + 1] = GRAD_READY_HOOK(l, grads[2 * l], grads[2 * l + 1])
+def _layer_done(grads, l, hook):
+    """hook(layer, dW, db), the second argument of SpectralMLP, is called as soon as a layer's weight and bias gradient
+    exist and returns the pair to hand to autograd (a data-parallel trainer copies them into a bucket and starts its
+    all-reduce there and then, so the collective overlaps the backward products of the layers below)."""
+    if hook is not None and grads[2 * l] is not None and grads[2 * l + 1] is not None:
+        grads[2 * l], grads[2 * l + 1] = hook(l, grads[2 * l], grads[2 * l + 1])
 
 
 class SpectralMLP(torch.autograd.Function):
@@ -149,11 +146,13 @@ class SpectralMLP(torch.autograd.Function):
     bias+ReLU ride in the epilogue of the wide forward products; the narrow output layer runs on the
     MFMA kernels (forward, weight gradient, input gradient fused with the previous layer's ReLU
     derivative and bias gradient); the first layer's backward is one pass that never writes the
-    masked gradient.  The wide products stay library GEMMs.  Arguments: x, W1, b1, ..., WL, bL."""
+    masked gradient.  The wide products stay library GEMMs.  Arguments: x, hook, W1, b1, ..., WL, bL (hook: None, or
+    a callable told of every layer's gradients during the backward, see _layer_done)."""
 
     @staticmethod
-    def forward(ctx, x, *params):
+    def forward(ctx, x, hook, *params):
         require_gpu(x.device)
+        ctx.hook = hook
         Ws, bs = params[0::2], params[1::2]
         acts = [x]
         for W, b in zip(Ws[:-1], bs[:-1]):
@@ -169,6 +168,7 @@ class SpectralMLP(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         L = ctx.n_layers
+        hook = ctx.hook
         saved = ctx.saved_tensors
         acts, y, Ws = saved[:L], saved[L], saved[L + 1:]
         grads = [None] * (2 * L)
@@ -177,11 +177,11 @@ class SpectralMLP(torch.autograd.Function):
         gp, db = act_bwd_bias(_f32c(gy), y, ACT_TANH)
         grads[2 * (L - 1)] = _wgrad(gp, acts[L - 1], Ws[L - 1])
         grads[2 * (L - 1) + 1] = db
-        _layer_done(grads, L - 1)
+        _layer_done(grads, L - 1, hook)
         gx = None
         if L == 1:
             gx = gp.mm(Ws[0]) if need_x else None
-            return (gx, *grads)
+            return (gx, None, *grads)
         # gradient reaching the output of hidden layer L-2: already multiplied by its ReLU derivative
         # (with its bias gradient) when the fused kernel applies, raw otherwise
         W, h = Ws[L - 1], acts[L - 1]
@@ -198,17 +198,17 @@ class SpectralMLP(torch.autograd.Function):
                         and xin.dtype == torch.float32 and pending.data_ptr() % 16 == 0):
                     dWt, db = first_layer_bwd(xin, pending, hout)
                     grads[0], grads[1] = dWt, db
-                    _layer_done(grads, 0)
-                    return (None, *grads)
+                    _layer_done(grads, 0, hook)
+                    return (None, None, *grads)
                 gp, db = act_bwd_bias(pending, hout, ACT_RELU)
             grads[2 * l] = _wgrad(gp, acts[l], Ws[l])
             grads[2 * l + 1] = db
-            _layer_done(grads, l)
+            _layer_done(grads, l, hook)
             if l > 0:
                 pending = gp.mm(Ws[l])
             elif need_x:
                 gx = gp.mm(Ws[0])
-        return (gx, *grads)
+        return (gx, None, *grads)
 
 
 def _wgrad(gp: torch.Tensor, xin: torch.Tensor, W: torch.Tensor) -> torch.Tensor:

@@ -70,34 +70,65 @@ def all_reduce_mean_gradients(params: Sequence[torch.nn.Parameter], group=None) 
 
 class LayerwiseReducer:
     """Gradient all-reduce that starts while the backward is still running: every MLP layer's weight and bias
-    gradient are packed into one small bucket the moment the backward has produced them and the bucket's
-    all-reduce is launched asynchronously (RCCL runs it on its own stream), so it overlaps the backward
-    products of the layers below; finish() waits for all buckets and turns the sums into means.  The
-    gradients handed back to autograd are views into the buckets."""
+    gradient are copied into that layer's bucket (allocated once, reused by every step) the moment the backward has
+    produced them and the bucket's all-reduce is launched asynchronously (RCCL runs it on its own stream), so it
+    overlaps the backward products of the layers below.  Autograd keeps the local gradients it was going to keep;
+    finish() waits for all buckets, turns the sums into means and makes every reported parameter's .grad a view into
+    its bucket -- by assignment, so nothing depends on how autograd stores what the backward returned.
 
-    def __init__(self, group=None):
+    params: [W0, b0, W1, b1, ...] in the order of the layer numbers the MLP reports.  Their .grad must be None when
+    the backward starts (zero_grad(set_to_none=True)): gradients that autograd accumulates in place would be added
+    into a bucket whose collective is in flight."""
+
+    def __init__(self, params: Optional[Sequence[torch.nn.Parameter]] = None, group=None):
         self.group = group
         self.world = dist.get_world_size(group)
+        self.params = list(params) if params is not None else None
+        self.buckets = {}
         self.pending = []
+        self.reduced = {}
+
+    def _bucket(self, layer: int, n: int, like: torch.Tensor) -> torch.Tensor:
+        flat = self.buckets.get(layer)
+        if flat is None or flat.numel() != n or flat.device != like.device or flat.dtype != like.dtype:
+            flat = torch.empty(n, dtype=like.dtype, device=like.device)
+            self.buckets[layer] = flat
+        return flat
 
     def on_layer(self, layer: int, dW: torch.Tensor, db: torch.Tensor):
-        flat = torch.cat([dW.reshape(-1), db.reshape(-1)])
+        if self.params is not None and (self.params[2 * layer].grad is not None or self.params[2 * layer + 1].grad is not None):
+            raise RuntimeError("LayerwiseReducer: clear the gradients with zero_grad(set_to_none=True) before the backward")
+        if any(layer == p[0] for p in self.pending):
+            raise RuntimeError("LayerwiseReducer: a layer reported its gradients twice in one backward (run both batches "
+                               "of a step through the MLP in one pass: SpectralNetModel.forward_pair)")
+        n = dW.numel()
+        flat = self._bucket(layer, n + db.numel(), dW)
+        flat[:n].view(dW.shape).copy_(dW)              # a transposed view is laid out as the parameter on the way
+        flat[n:].view(db.shape).copy_(db)
         if _staged(flat, self.group):          # gloo rehearsal on a GPU: through the host, synchronously
             all_reduce_sum(flat, self.group)
             work = None
         else:
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self.pending.append((work, flat))
-        n = dW.numel()
-        return flat[:n].view_as(dW), flat[n:].view_as(db)
+        self.pending.append((layer, work, flat, dW.shape, db.shape))
+        return dW, db
 
     def finish(self) -> int:
-        """Wait for every bucket and average; returns the number of buckets reduced."""
+        """Wait for every bucket, average, and hand the means to the parameters; returns the number of buckets
+        reduced.  reduced[layer] = (dW, db) holds the averaged pair (views into the layer's bucket) until the next
+        step's backward overwrites the bucket."""
         done = len(self.pending)
-        for work, flat in self.pending:
+        self.reduced = {}
+        for layer, work, flat, w_shape, b_shape in self.pending:
             if work is not None:
                 work.wait()
             flat.div_(self.world)
+            n = flat.numel() - int(np.prod(b_shape))
+            gW, gb = flat[:n].view(w_shape), flat[n:].view(b_shape)
+            self.reduced[layer] = (gW, gb)
+            if self.params is not None:
+                self.params[2 * layer].grad = gW
+                self.params[2 * layer + 1].grad = gb
         self.pending = []
         return done
 
@@ -135,9 +166,19 @@ class ShardedSpectralTrainer:
             self.optimizer = torch.optim.Adam(self.net.parameters(), lr=lr, fused=fused_adam)
         self._graphed = None
         self.criterion = criterion
-        self.reducer = LayerwiseReducer(group) if self.distributed else None
+        self.reducer = None
+        if self.distributed:
+            self.attach_reducer(LayerwiseReducer(self.params, group))
         self.features = []
         self.batches = []
+
+    def attach_reducer(self, reducer: LayerwiseReducer):
+        """Average the gradients through this reducer: a model that reports its layers during the backward
+        (SpectralNetModel.grad_ready_hook) feeds it layer by layer; for any other model step() falls back to one
+        bucket after the backward."""
+        self.reducer = reducer
+        if hasattr(self.net, "grad_ready_hook"):
+            self.net.grad_ready_hook = reducer.on_layer
 
     def add_batch(self, features: torch.Tensor, batch) -> int:
         self.features.append(features.to(self.device, dtype=torch.float32).contiguous())
@@ -147,9 +188,8 @@ class ShardedSpectralTrainer:
     def step(self, pid: int, pid_2: int, top_idx=None) -> torch.Tensor:
         """Orthogonality step on local batch pid_2, gradient step on local batch pid
         (src/SpectralTrainer.py:216-238), gradient averaged over the ranks before Adam: layer by layer
-        while the backward runs when the MLP reports its layers (ops.GRAD_READY_HOOK), in one bucket after
+        while the backward runs when the MLP reports its layers (SpectralNetModel.grad_ready_hook), in one bucket after
         the backward otherwise."""
-        from . import ops
         if self.hip_graph:
             if self._graphed is None:
                 from .stepgraph import GraphedSteps
@@ -161,12 +201,7 @@ class ShardedSpectralTrainer:
         self.optimizer.zero_grad(set_to_none=True)   # autograd hands its gradients over as they are: no accumulation
         Y = net.forward_pair(self.features[pid_2], self.features[pid], top_idx=top_idx)
         loss = self.criterion(self.batches[pid], Y, is_normalized=True)
-        if self.distributed:
-            ops.GRAD_READY_HOOK = self.reducer.on_layer
-        try:
-            loss.backward()
-        finally:
-            ops.GRAD_READY_HOOK = None
+        loss.backward()
         if self.distributed and self.reducer.finish() == 0:
             all_reduce_mean_gradients(self.params, self.group)   # no layer reported: one bucket, one collective
         self.optimizer.step()

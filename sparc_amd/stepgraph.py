@@ -53,23 +53,25 @@ class GraphedSteps:
         self.orth.copy_(self.net.orthonorm_weights.detach())
         return loss.detach()
 
-    def _stage(self, top_idx):
+    def _stage(self, top_idx, m2: int):
         slot = self._turn % self.RING
         self._turn += 1
         if self._free[slot] is not None:
             self._free[slot].synchronize()
-        head = np.zeros(self.k, np.int32) if top_idx is None else np.asarray(top_idx, dtype=np.int32)[:self.k]
-        if top_idx is None:
-            head[:] = np.arange(self.k)
-        self._host[slot].numpy()[:] = head
+        head = np.arange(self.k, dtype=np.int32) if top_idx is None else np.asarray(top_idx, dtype=np.int32)[:self.k]
+        buf = self._host[slot].numpy()
+        # an orthogonality batch of fewer than k rows leaves the tail without a row: its row count is the index that
+        # reads as a row of zeros (as ops.OrthWeights pads it)
+        buf[:] = m2
+        buf[:head.shape[0]] = head
         self.top_idx.copy_(self._host[slot], non_blocking=True)
         ev = torch.cuda.Event()
-        ev.record()
+        ev.record(torch.cuda.current_stream(self.device))
         self._free[slot] = ev
 
     def step(self, pid: int, pid_2: int, top_idx=None) -> torch.Tensor:
         self.net.train()
-        self._stage(top_idx)
+        self._stage(top_idx, int(self.features[pid_2].shape[0]))
         key = (pid, pid_2)
         hit = self.graphs.get(key)
         if hit is None and len(self.graphs) >= self.MAX_GRAPHS:

@@ -52,7 +52,7 @@ def check_mlp(seed):
     params = [p for lin in lins for p in (lin.weight, lin.bias)]
     wrt = params + ([x] if x_grad else [])
     rg = torch.autograd.grad((ref * t).sum(), wrt)
-    out = SpectralMLP.apply(x, *params)
+    out = SpectralMLP.apply(x, None, *params)
     og = torch.autograd.grad((out * t).sum(), wrt)
     d = f"dims {dims} m {m} x_grad {x_grad}"
     note("mlp forward", rel(out.detach().cpu().numpy(), ref.detach().cpu().numpy()), 2e-5, seed, d)

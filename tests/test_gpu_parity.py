@@ -127,6 +127,35 @@ def test_affinity_and_loss_match_reference_golden(dev, golden, name):
     assert rel(Yg.grad.cpu().numpy(), gref.numpy()) < TOL
 
 
+@pytest.mark.parametrize("name", ["raw", "rownorm", "enh"])
+def test_loss_accepts_the_dense_affinity_of_the_reference_signature(dev, golden, name):
+    """SpectralNetLoss.forward(W, Y, is_normalized) with W the dense m x m affinity, as src/SpectralTrainer.py:116
+    receives it from _get_valid_affinity_matrix (:284-293): both branches and the gradient with respect to Y, against
+    the losses the reference printed for the same support, and the dense helper against the oracle's dense affinity."""
+    from sparc_amd.SpectralTrainer import SpectralNetLoss, SpectralTrainer
+    g = golden("g2_affinity_loss.npz")
+    A = O.support_to_dense(sup(g, name + "_"), torch.float32)
+    W_ref = O.valid_affinity(A.double())
+    cfg = {"dataset": "x", "spectral": {"lr": 1e-3, "epochs": 1, "lr_decay": 0.1, "patience": 1, "batch_size": 1,
+                                        "architecture": {}, "n_clusters": 1}}
+    W = SpectralTrainer(cfg, dev)._get_valid_affinity_matrix(A.to(dev))
+    assert W.dtype == torch.float32 and rel(W.cpu().numpy(), W_ref.numpy()) < 1e-5
+    assert rel(W.sum(1).cpu().numpy(), g[name + "_d"]) < TOL
+    Y = torch.tensor(g["Y"], device=dev, requires_grad=True)
+    loss = SpectralNetLoss()(W, Y, is_normalized=True)
+    assert loss.dtype == torch.float32 and rel(loss.item(), g[name + "_loss_norm"]) < TOL
+    loss.backward()
+    Yd = torch.tensor(g["Y"], dtype=torch.float64, requires_grad=True)
+    (gref,) = torch.autograd.grad(O.spectral_loss(W_ref, Yd, True), Yd)
+    assert rel(Y.grad.cpu().numpy(), gref.numpy()) < TOL
+    plain = SpectralNetLoss()(W, Y.detach())
+    assert rel(plain.item(), g[name + "_loss_plain"]) < TOL
+    with pytest.raises(TypeError):
+        SpectralNetLoss()(W[:-1], Y.detach())          # not the batch's m x m matrix
+    with pytest.raises(TypeError):
+        SpectralNetLoss()("W", Y.detach())
+
+
 @pytest.mark.parametrize("k", [1, 8, 16, 17, 32, 47, 64])
 @pytest.mark.parametrize("flavour", ["raw", "enh"])
 def test_lap_loss_and_grad_match_oracle(dev, k, flavour):
@@ -424,7 +453,7 @@ def test_spectral_mlp_matches_torch_layers(dev, dims, x_grad):
     params = [p for lin in lins for p in (lin.weight, lin.bias)]
     wrt = params + ([x] if x_grad else [])
     rg = torch.autograd.grad((ref * t).sum(), wrt)
-    out = SpectralMLP.apply(x, *params)
+    out = SpectralMLP.apply(x, None, *params)
     og = torch.autograd.grad((out * t).sum(), wrt)
     assert rel(out.detach().cpu().numpy(), ref.detach().cpu().numpy()) < 1e-5
     for a, b in zip(og, rg):
@@ -508,7 +537,7 @@ def test_weight_gradient_summed_in_parts(dev, monkeypatch):
     for split_rows in (16384, 1 << 40):
         monkeypatch.setattr(ops, "WGRAD_SPLIT_ROWS", split_rows)
         n0 = len(calls)
-        grads[split_rows] = torch.autograd.grad((ops.SpectralMLP.apply(xin, *params) * t).sum(), params)
+        grads[split_rows] = torch.autograd.grad((ops.SpectralMLP.apply(xin, None, *params) * t).sum(), params)
         assert (len(calls) > n0) == (split_rows == 16384)
     for a, b in zip(grads[16384], grads[1 << 40]):
         assert rel(a.cpu().numpy(), b.cpu().numpy()) < 2e-5
@@ -1028,6 +1057,33 @@ def test_hip_graph_steps_match_eager_steps(dev, monkeypatch):
         # with the same optimiser arithmetic the replayed steps are the eager steps bit for bit
         assert np.array_equal(runs[mode][0], runs["same optimiser"][0])
         assert np.array_equal(runs[mode][1], runs["same optimiser"][1])
+
+
+def test_hip_graph_step_with_fewer_rows_than_dimensions(dev):
+    """An orthogonality batch of fewer than k rows (its Gram matrix cannot be positive definite: the reference's
+    torch.inverse fails on it) goes through the graphed step as through the eager one: the permutation head is padded
+    with the out-of-range row that reads as zeros, and the failure is reported by the same flag, not by an exception
+    of the staging."""
+    from sparc_amd.graph import ClusterBatch
+    from sparc_amd.ops import OrthWeights
+    from sparc_amd.parallel import ShardedSpectralTrainer
+    k, din = 12, 6
+    arch = {"n_layers": 4, "hidden_dim1": 32, "hidden_dim2": 32, "hidden_dim3": 16, "output_dim": k}
+    rng = np.random.default_rng(0)
+    sizes = (40, 8)                                   # the second batch has 8 < k rows
+    for graphed in (False, True):
+        tr = ShardedSpectralTrainer(arch, din, dev, lr=1e-3, seed=1, hip_graph=graphed)
+        for m in sizes:
+            A = sp.random(m, m, density=0.3, random_state=np.random.RandomState(m), format="csr")
+            A.data[:] = 1.0
+            A = sp.csr_matrix(sp.triu(A, 1) + sp.triu(A, 1).T + sp.eye(m))
+            tr.add_batch(torch.tensor(rng.standard_normal((m, din)), dtype=torch.float32), ClusterBatch.from_support(O.as_support_tuple(A), dev))
+        OrthWeights.check_and_reset(dev)
+        loss_ok = tr.step(0, 0, np.random.RandomState(1).permutation(sizes[0])[:k])
+        assert np.isfinite(float(loss_ok)) and OrthWeights.check_and_reset(dev) == 0
+        for _ in range(2):                            # eager first visit, then the replay
+            tr.step(0, 1, np.random.RandomState(2).permutation(sizes[1])[:k])
+        assert OrthWeights.check_and_reset(dev) != 0
 
 
 def test_training_separates_planted_clusters(dev, tmp_path, monkeypatch, capsys):

@@ -114,11 +114,30 @@ def _trainer_worker(rank, world, port, out):
     w = torch.cat([p.detach().flatten() for p in tr.params])
     val = float(tr.validation_loss([feats[b] for b in mine], [mats[b] @ mats[b].t() for b in mine]))
     # the layer-wise reducer on its own: buckets launched one by one, averaged on finish
-    red = LayerwiseReducer()
+    lin = [torch.nn.Linear(4, 3), torch.nn.Linear(4, 3)]
+    red = LayerwiseReducer([p for l in lin for p in (l.weight, l.bias)])
     gW, gb = torch.full((3, 4), float(rank + 1)), torch.full((3,), float(10 * (rank + 1)))
-    vW, vb = red.on_layer(0, gW, gb)
-    vW2, _ = red.on_layer(1, gW * 2, gb)
+    kept = red.on_layer(0, gW, gb)
+    assert kept[0] is gW and kept[1] is gb          # autograd keeps the local pair; the means arrive through finish()
+    red.on_layer(1, (gW * 2).t().contiguous().t(), gb)   # a gradient that arrives as a transposed view
+    try:
+        red.on_layer(1, gW, gb)
+        raise AssertionError("a layer reported twice must be refused")
+    except RuntimeError:
+        pass
     n_done = red.finish()
+    (vW, vb), (vW2, _) = red.reduced[0], red.reduced[1]
+    assert lin[0].weight.grad.data_ptr() == vW.data_ptr() and lin[1].bias.grad is red.reduced[1][1]
+    first_bucket = red.buckets[0].data_ptr()
+    lin[0].weight.grad = lin[0].bias.grad = None
+    red.on_layer(0, gW, gb)                          # the next step reuses the layer's bucket
+    red.finish()
+    assert red.buckets[0].data_ptr() == first_bucket and torch.equal(lin[0].weight.grad, vW)
+    try:
+        red.on_layer(0, gW, gb)                      # gradients not cleared: refused
+        raise AssertionError("a stale .grad must be refused")
+    except RuntimeError:
+        pass
     gathered = [torch.zeros_like(w) for _ in range(world)]
     dist.all_gather(gathered, w)
     g0 = [torch.zeros_like(w0) for _ in range(world)]
@@ -169,3 +188,125 @@ def test_sharded_trainer_step_world2():
     want = torch.cat([p.detach().flatten() for p in net.parameters()]).numpy()
     assert np.allclose(res["w"][0], want, rtol=1e-5, atol=1e-6)
     assert np.isfinite(res["val"]) and all(np.isfinite(res["losses"]))
+
+
+# ---- SpectralTrainer.train inside a process group (the epoch loop on CPU stand-ins) ------------------------------
+def _make_problem():
+    gen = torch.Generator().manual_seed(11)
+    feats = [torch.randn(10 + b, 5, generator=gen) for b in range(5)]
+    mats = [torch.randn(10 + b, 10 + b, generator=gen) for b in range(5)]
+    vfeats = [torch.randn(9 + b, 5, generator=gen) for b in range(3)]
+    vmats = [torch.randn(9 + b, 9 + b, generator=gen) for b in range(3)]
+    psd = lambda m: m @ m.t()
+    return feats, [psd(m) for m in mats], vfeats, [psd(m) for m in vmats]
+
+
+_EPOCH_CFG = {"dataset": "gloo_epochs", "spectral": {"lr": 1e-2, "epochs": 3, "lr_decay": 0.1, "patience": 10, "min_lr": 1e-8,
+                                                   "batch_size": 1, "n_clusters": 3, "architecture": {"output_dim": 3}}}
+
+
+def _epoch_trainer(tmpdir):
+    from sparc_amd.SpectralTrainer import SpectralTrainer
+
+    class StubTrainer(SpectralTrainer):
+        def _setup_model(self, input_dim):
+            self.criterion = _stub_loss
+            self.spectral_net = _StubNet()
+
+        def _get_valid_affinity_matrix(self, W, X=None):
+            return W
+
+    tr = StubTrainer(_EPOCH_CFG, torch.device("cpu"))
+    tr.weights_path = os.path.join(tmpdir, "w", "spectralnet_weights.pth")
+    tr.orth_weights_path = os.path.join(tmpdir, "w", "orth.pth")
+    return tr
+
+
+def _epochs_worker(rank, world, port, tmpdir, out):
+    import contextlib
+    import io
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    feats, mats, vfeats, vmats = _make_problem()
+    torch.manual_seed(50 + rank)                 # different initial weights: rank 0's must win
+    np.random.seed(0)
+    tr = _epoch_trainer(os.path.join(tmpdir, f"rank{rank}"))
+    tr._setup_model(5)
+    tr.spectral_net.orthonorm_weights = torch.eye(3)
+    tr._setup_optimizer(False)
+    mine, mine_val = tr._my_share(5, 3, world, rank)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        net = tr._run_epochs([feats[b] for b in mine], [mats[b] for b in mine], [vfeats[b] for b in mine_val],
+                             [vmats[b] for b in mine_val], 3, n_val_total=3)
+    w = torch.cat([p.detach().flatten() for p in net.parameters()])
+    allw = [torch.zeros_like(w) for _ in range(world)]
+    dist.all_gather(allw, w)
+    out.put((rank, buf.getvalue(), torch.stack(allw).numpy(), os.path.exists(tr.weights_path), mine, mine_val))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_spectral_trainer_epochs_world2(tmp_path):
+    """SpectralTrainer's epoch loop on two gloo ranks (stand-in model and loss on the CPU): five training batches dealt
+    3 + 2, three validation batches dealt 2 + 1; both replicas end with the same weights, which are those of one
+    process that plays both ranks (same draws, gradients averaged by hand); the printed losses are the sums over
+    both ranks; rank 0 alone prints and writes the checkpoint."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_epochs_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=180) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, out0, w0, saved0, mine0, val0), (_, out1, w1, saved1, mine1, val1) = got
+    assert mine0 == [0, 2, 4] and mine1 == [1, 3] and val0 == [0, 2] and val1 == [1]
+    assert np.array_equal(w0[0], w0[1]) and np.array_equal(w0, w1)
+    assert saved0 and not saved1 and out1 == ""
+    lines = [l for l in out0.splitlines() if l.startswith("Epoch")]
+    assert out0.startswith("Training SpectralNet:") and len(lines) == 3
+
+    # one process playing both ranks
+    feats, mats, vfeats, vmats = _make_problem()
+    torch.manual_seed(50)
+    net = _StubNet()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-2)
+    shares = [[0, 2, 4], [1, 3]]
+    rs = [np.random.RandomState(0), np.random.RandomState(0)]
+    want_lines = []
+    for epoch in range(3):
+        total = 0.0
+        for step in range(3):
+            opt.zero_grad()
+            loss_sum = 0
+            for r in range(2):
+                nb = len(shares[r])
+                pid = step % nb
+                pid_2 = rs[r].choice(nb)
+                b1, b2 = shares[r][pid], shares[r][pid_2]
+                rs[r].permutation(len(feats[b1]))
+                rs[r].permutation(len(feats[b2]))
+                l = _stub_loss(mats[b1], net.forward_pair(feats[b2], feats[b1]))
+                total += float(l.detach())
+                loss_sum = loss_sum + l / 2
+            loss_sum.backward()
+            opt.step()
+        with torch.no_grad():
+            vl = sum(float(_stub_loss(vmats[b], net(vfeats[b]))) for b in range(3))
+        want_lines.append((total / 6, vl / 3))
+    want = torch.cat([p.detach().flatten() for p in net.parameters()]).numpy()
+    assert np.allclose(w0[0], want, rtol=1e-5, atol=1e-6)
+    import re
+    for line, (tl, vl) in zip(lines, want_lines):
+        nums = [float(x) for x in re.findall(r"[-+]?\d+\.\d+", line)]
+        assert abs(nums[0] - tl) <= 1e-5 * max(1, abs(tl)) and abs(nums[1] - vl) <= 1e-5 * max(1, abs(vl)), (line, tl, vl)
+
+
+def test_more_ranks_than_batches_still_gives_every_rank_work():
+    from sparc_amd.SpectralTrainer import SpectralTrainer
+    assert SpectralTrainer._my_share(2, 1, 4, 3) == ([1], [])
+    assert SpectralTrainer._my_share(2, 1, 4, 0) == ([0], [0])
+    assert SpectralTrainer._my_share(100, 20, 8, 7) == (list(range(7, 100, 8)), [7, 15])

@@ -56,3 +56,30 @@ def test_gram_static_rejects_what_it_cannot_hold():
     G = torch.zeros(65, 65, dtype=torch.float64, device=dev)
     assert lib.sparc_gram_static(8, 65, _ptr(A), 65, _ptr(A), 65, _ptr(G), None) == -4      # SPARC_ERR_SIZE
     assert lib.sparc_gram_static(0, 8, _ptr(A), 65, _ptr(A), 65, _ptr(G), None) == -1       # SPARC_ERR_ARG
+
+
+def test_gram_static_under_stream_capture():
+    """After sparc_init() on the device the entry point makes no runtime query: captured into a HIP graph and replayed
+    on new operand contents it gives sparc_gram's result bit for bit."""
+    from sparc_amd._lib import init_device, lib
+    dev = torch.device("cuda:0")
+    init_device(0)
+    m, k = 5000, 47
+    gen = torch.Generator(device=dev).manual_seed(9)
+    A = torch.randn(m, k, device=dev, generator=gen)
+    B = torch.randn(m, k, device=dev, generator=gen)
+    G = torch.zeros(k, k, dtype=torch.float64, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        rc = lib.sparc_gram_static(m, k, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(G),
+                                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    for seed in (1, 2):
+        A.copy_(torch.randn(m, k, device=dev, generator=gen))
+        B.copy_(torch.randn(m, k, device=dev, generator=gen))
+        g.replay()
+        torch.cuda.synchronize()
+        ref, _ = _gram_pair(lib, A, B, k)
+        assert np.array_equal(G.cpu().numpy(), ref)
