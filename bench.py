@@ -260,6 +260,9 @@ def main():
     log(f"[bench] graph: {n} nodes, {int(graph.indices.numel())} stored entries, {len(nodes_of)} batches, {t_graph:.1f}s")
 
     mine = shard_batches(len(nodes_of), world, rank)[:args.batches_per_rank]
+    if not mine:
+        raise SystemExit(f"rank {rank} is left without a batch: the graph has {len(nodes_of)} batches for {world} ranks "
+                         f"(raise --scale)")
     trainer = ShardedSpectralTrainer(arch, din, dev, lr=1e-3, seed=0, hip_graph=args.hip_graph)
     t0 = time.perf_counter()
     for b in mine:

@@ -12,6 +12,15 @@ enum SpmmEpilogue {
     EPI_PREP_ACC = 5,    // row statistics of S[:, col0 : col0 + W)
 };
 
+// The column-sum finish of the Laplacian chain (spmm.hip: colsum_finish_body), which the first inner pass can
+// carry spread over its workgroups; colpart == null: none.
+struct ColsumFinish {
+    const float* colpart;    // [nparts][6][kp] block partials of lap_scale
+    const double* coupling;  // the 3 x 3 coupling
+    float* M12;              // [6][kp] + 9
+    int kp, nparts, dual;
+};
+
 struct SpmmArgs {
     int64_t m;
     int64_t nnz;
@@ -28,6 +37,10 @@ struct SpmmArgs {
     const float* rowc;  // [m][SPARC_ROWC]
     const float* M12;   // [6][KP]
     double* loss_part;  // one per block
+    double* loss_out;   // the last workgroup to arrive writes loss_scale * (sum of loss_part) here
+    double loss_scale;
+    int chain_slot;     // which set of arrival counters this call uses
+    ColsumFinish fin;   // EPI_ADD_X0: workgroup c < fin.kp also finishes column c of the column sums
     float* gradY;
     int64_t ldy;
     int k;

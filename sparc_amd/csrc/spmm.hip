@@ -17,6 +17,7 @@
 //
 // In "dual" mode X is [Yn | Yn/rho]: the left half is multiplied by A (val), the right half
 // by A^T (valT, same pattern), so W Yn and W^T Yn share one pass over the index stream.
+#include <atomic>
 #include <cstdint>
 #include <cstdlib>
 #include <mutex>
@@ -29,6 +30,181 @@ namespace {
 constexpr int ROWS_PER_BLOCK = 4;  // spmm_rows: one row per wave
 constexpr int WIN_MAX_THREADS = 1024;  // spmm_win: workgroup size is a launch parameter, up to 16 waves
 constexpr int WIN_MAX_RECORDS = SPARC_TILE_MAX_RECORDS;  // rows of one workgroup (their records sit in LDS)
+
+// ------------------------------------------------------------------ last workgroup done
+// The loss partials of the windowed kernel's last pass are summed by whichever workgroup arrives last instead of
+// by a kernel of their own.  The arrival counters are part of the library image (zero when it is loaded, and put
+// back to zero by the workgroup that finishes); a call takes the next of CHAIN_SLOTS sets, so calls that overlap on
+// one device (other streams) count separately as long as fewer than CHAIN_SLOTS of them are in flight.  (The row
+// kernel keeps its finishing launch: with one workgroup per four rows the arrivals cost more than the launch,
+// 6 k workgroups: 39 + 5 us as two launches, 50 us as one.)
+constexpr int CHAIN_SLOTS = 256;
+constexpr int CHAIN_SUBS = 64;                 // second-level counters of a large grid, one cache line each
+constexpr int CHAIN_LINE = 32;                 // words per 128-byte line
+constexpr int CHAIN_WORDS = (1 + CHAIN_SUBS) * CHAIN_LINE;   // per slot: the counter and its sub-counters
+__device__ unsigned int g_chain_counter[CHAIN_SLOTS * CHAIN_WORDS];
+std::atomic<unsigned int> g_chain_next{0};
+
+// Partial results travel between workgroups through device-scope atomic stores and loads (write-through and
+// read-through the per-XCD L2s), so that no workgroup has to write back or invalidate a whole L2, which is what a
+// device-scope fence costs here (measured: 17 -> 98 us for the last pass with a fence per workgroup).
+__device__ __forceinline__ void publish(double* p, const double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double collect(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Called by every thread of every workgroup of the grid after the workgroup's partial results are published.
+// Returns true, in all threads, in the one workgroup that arrives last; there every other workgroup's
+// partial results can be collected.  `flag` is a word of LDS.
+__device__ __forceinline__ bool arrive_last(unsigned int* counter, unsigned int* subs, const unsigned int total, unsigned int* flag) {
+    // this thread's published stores have completed (the fence keeps the compiler from moving them; the wait is
+    // for the write-through stores themselves: vmcnt(0)) ...
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();                                         // ... and so have those of the rest of the workgroup
+    if (threadIdx.x == 0) {
+        // One atomic per workgroup costs about 7 ns when they all hit one word (measured: 6 k workgroups of the row
+        // kernel, +45 us), so a grid of more than 2 CHAIN_SUBS workgroups counts in two levels: workgroup b arrives at
+        // sub-counter b mod CHAIN_SUBS (`subs`: they follow `counter`, a line apart), and the last arrival of every
+        // sub-counter at `counter` itself.
+        bool last;
+        if (subs && total > 2 * CHAIN_SUBS) {
+            const unsigned int j = blockIdx.x % CHAIN_SUBS;
+            const unsigned int mine = (total - j + CHAIN_SUBS - 1) / CHAIN_SUBS;   // workgroups b = j (mod CHAIN_SUBS), b < total
+            unsigned int* sub = subs + j * CHAIN_LINE;
+            last = __hip_atomic_fetch_add(sub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == mine;
+            if (last) {
+                __hip_atomic_store(sub, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == CHAIN_SUBS;
+            }
+        } else {
+            last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == total;
+        }
+        if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // everybody has arrived: ready for the next call
+        *flag = last ? 1u : 0u;
+    }
+    __syncthreads();
+    const bool last = *flag != 0u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return last;
+}
+
+// loss = scale * (sum of the grid's loss partials), summed in a fixed order by the last workgroup
+__device__ __forceinline__ void finish_loss(const SpmmArgs& a, const unsigned int nparts, double* wl, unsigned int* flag) {
+    unsigned int* c = g_chain_counter + static_cast<size_t>(a.chain_slot) * CHAIN_WORDS;
+    if (!arrive_last(c, c + CHAIN_LINE, gridDim.x, flag)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    double t = 0.0;
+    for (unsigned int i = threadIdx.x; i < nparts; i += blockDim.x) t += collect(a.loss_part + i);
+    t = wave_sum(t);
+    if (lane == 0) wl[wave] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sum = 0.0;
+        for (int w = 0; w < nwaves; ++w) sum += wl[w];
+        *a.loss_out = sum * a.loss_scale;
+    }
+}
+
+// M1 = C (V^T Yn), M2 = C^T (U^T X2): the 3 x KP matrices of the rank-3 correction, from the block partials of
+// lap_scale (M12 = [M1; M2; the 3 x 3 coupling]).  Work of ONE workgroup of any size: the partials of one column
+// sum are dealt to `split` threads (fixed assignment, eight independent chains each) and combined in a fixed
+// order; S is LDS for FINISH_SPLIT x 6 x SPARC_MAX_K doubles.  (The stand-alone kernel: the dense-block path and
+// shapes that FinishShare does not take.)
+constexpr int FINISH_SPLIT = 4;
+__device__ __forceinline__ void colsum_finish_body(const ColsumFinish& f, double* S) {
+    const int KP = f.kp, n = 6 * KP, nt = blockDim.x;
+    const int split = max(1, min(FINISH_SPLIT, nt / n));
+    const int ns = f.dual ? 6 : 3;
+    for (int idx = threadIdx.x; idx < n * split; idx += nt) {
+        const int e = idx % n, share = idx / n;
+        const int q = e / KP, col = e % KP;
+        if (q < ns) {
+            double t[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // eight independent chains, fixed order
+            int b = share;
+            for (; b + 7 * split < f.nparts; b += 8 * split) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] += f.colpart[(static_cast<int64_t>(b + u * split) * 6 + q) * KP + col];
+            }
+            for (; b < f.nparts; b += split) t[0] += f.colpart[(static_cast<int64_t>(b) * 6 + q) * KP + col];
+            S[(share * 6 + q) * SPARC_MAX_K + col] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < n; e += nt) {
+        const int q = e / KP, col = e % KP;
+        if (q >= ns) continue;
+        double t = 0.0;
+        for (int b = 0; b < 3; ++b) {
+            const int src = q < 3 ? b : 3 + b;
+            double sum = S[src * SPARC_MAX_K + col];
+            for (int h = 1; h < split; ++h) sum += S[(h * 6 + src) * SPARC_MAX_K + col];
+            t += (q < 3 ? f.coupling[q * 3 + b] : f.coupling[b * 3 + (q - 3)]) * sum;
+        }
+        f.M12[q * KP + col] = static_cast<float>(t);
+    }
+    if (threadIdx.x < 9) f.M12[6 * KP + threadIdx.x] = static_cast<float>(f.coupling[threadIdx.x]);
+}
+
+// The same finish spread over the workgroups of the first inner pass (the last pass of the chain is the first
+// reader of M12, so it has a whole pass of time): workgroup c < KP owns column c, its wave w the sum over the block
+// partials of row w of the six (V^T Yn: 0-2, U^T X2: 3-5): a lane requests two partials when the kernel starts
+// (at most 128 partials: lap_scale's block limit) and the sums are formed after the workgroup's own work, so the
+// loads cost the pass nothing.  NQ: sums per wave (workgroups of fewer than six waves take two).  One extra
+// workgroup doing all of it was tried first and became the pass's tail (14.4 -> 21.8 us).
+template <int NQ>
+struct FinishShare {
+    float v[NQ][2];
+    __device__ __forceinline__ void request(const ColsumFinish& f, const int wave, const int lane, const int nwaves) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            v[j][0] = v[j][1] = 0.f;
+            const int q = wave + j * nwaves;
+            if (f.colpart && static_cast<int>(blockIdx.x) < f.kp && q < (f.dual ? 6 : 3)) {
+                const float* src = f.colpart + static_cast<int64_t>(q) * f.kp + blockIdx.x;
+                if (lane < f.nparts) v[j][0] = src[static_cast<int64_t>(lane) * 6 * f.kp];
+                if (lane + 64 < f.nparts) v[j][1] = src[static_cast<int64_t>(lane + 64) * 6 * f.kp];
+            }
+        }
+    }
+    // sums: LDS for six doubles; every thread of the workgroup calls this (it holds a barrier)
+    __device__ __forceinline__ void finish(const ColsumFinish& f, const int wave, const int lane, const int nwaves, double* sums) const {
+        if (!f.colpart || static_cast<int>(blockIdx.x) >= f.kp) return;   // uniform over the workgroup
+        const int ns = f.dual ? 6 : 3;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const int q = wave + j * nwaves;
+            const double t = wave_sum(static_cast<double>(v[j][0]) + static_cast<double>(v[j][1]));
+            if (lane == 0 && q < ns) sums[q] = t;
+        }
+        __syncthreads();
+        if (static_cast<int>(threadIdx.x) < ns) {
+            const int q = threadIdx.x;
+            double t = 0.0;
+            for (int b = 0; b < 3; ++b) t += (q < 3 ? f.coupling[q * 3 + b] : f.coupling[b * 3 + (q - 3)]) * sums[q < 3 ? b : 3 + b];
+            f.M12[q * f.kp + blockIdx.x] = static_cast<float>(t);
+        }
+        if (blockIdx.x == 0 && threadIdx.x >= 64 && threadIdx.x < 73) f.M12[6 * f.kp + threadIdx.x - 64] = static_cast<float>(f.coupling[threadIdx.x - 64]);
+        __syncthreads();   // `sums` may be reused by the caller
+    }
+};
+
+__global__ __launch_bounds__(1024) void lap_colsum_finish(const ColsumFinish f) {
+    __shared__ double S[FINISH_SPLIT * 6 * SPARC_MAX_K];
+    colsum_finish_body(f, S);
+}
+
+__global__ __launch_bounds__(256) void loss_finish(int64_t n, const double* __restrict__ part, double scale,
+                                                   double* __restrict__ loss) {
+    __shared__ double sm[256];
+    double t = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) t += part[i];
+    sm[threadIdx.x] = t;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = sm[0] * scale;
+}
 
 // ------------------------------------------------------------------ shared epilogue
 // A lane owns VEC consecutive columns of one row: `cl` is their index inside the half (0..kp-1),
@@ -291,6 +467,12 @@ template <int LR, bool DUAL, int EPI>
 __global__ __launch_bounds__(256) void spmm_rows(const SpmmArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    if (EPI == EPI_ADD_X0) {   // this workgroup's share of the column-sum finish, out of the way before the rows
+        __shared__ double fs[6];
+        FinishShare<2> fin;
+        fin.request(a.fin, wave, lane, 4);
+        fin.finish(a.fin, wave, lane, 4, fs);
+    }
     double wloss = 0.0;
     for (int rr = wave; rr < ROWS_PER_BLOCK; rr += 4) {
         const int64_t row = blk * ROWS_PER_BLOCK + rr;
@@ -517,8 +699,19 @@ __global__ __launch_bounds__(WIN_MAX_THREADS) void spmm_win(const SpmmArgs a) {
     const int g = lane >> 4, lr = lane & 15;
     const int32_t* d = a.desc + static_cast<int64_t>(blockIdx.x) * 8;
     const int s_begin = d[0], s_end = d[1], w0 = d[2], wn = d[3] - d[2], slab = d[4], n_long = d[5];
-    if (s_end <= s_begin) {  // padding descriptor
-        if ((EPI == EPI_LAP_SINGLE || EPI == EPI_LAP_DUAL) && threadIdx.x == 0) a.loss_part[blockIdx.x] = 0.0;
+    __shared__ double wl[WIN_MAX_THREADS / 64];
+    __shared__ unsigned int last_flag;
+    // this workgroup's share of the column-sum finish: requested now, summed behind the staging barrier (the
+    // loads travel with the staging copies; held any longer they cost the slot loop its register budget: 80 -> 86
+    // registers, one workgroup per CU instead of two, 14.4 -> 18.6 us)
+    FinishShare<1> fin;
+    if (EPI == EPI_ADD_X0) fin.request(a.fin, wave, lane, nwaves);
+    if (s_end <= s_begin) {  // padding descriptor: nothing to add, but the workgroup is counted
+        if (EPI == EPI_ADD_X0) fin.finish(a.fin, wave, lane, nwaves, wl);
+        if (EPI == EPI_LAP_SINGLE || EPI == EPI_LAP_DUAL) {
+            if (threadIdx.x == 0) publish(a.loss_part + blockIdx.x, 0.0);
+            finish_loss(a, gridDim.x, wl, &last_flag);
+        }
         return;
     }
     // columns of this lane inside its half (dual: 8 lanes for the A half, 8 for the A^T half)
@@ -553,6 +746,7 @@ __global__ __launch_bounds__(WIN_MAX_THREADS) void spmm_win(const SpmmArgs a) {
     if (PAT && threadIdx.x < RW) reinterpret_cast<float*>(tile)[wn * RW + threadIdx.x] = 0.f;  // the row padding entries point at
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's copies into LDS have landed
     __syncthreads();                     // ... and so have everybody else's
+    if (EPI == EPI_ADD_X0) fin.finish(a.fin, wave, lane, nwaves, wl);
     if (a.stamps) t_bar = __builtin_readcyclecounter();
 
     // A wave owns slots wave, wave + nwaves, ... sorted by work (longest first) and dealt in serpentine
@@ -673,15 +867,15 @@ __global__ __launch_bounds__(WIN_MAX_THREADS) void spmm_win(const SpmmArgs a) {
         st[0] = t_start; st[1] = t_bar; st[2] = __builtin_readcyclecounter(); st[3] = nslots;
     }
     if (EPI == EPI_LAP_SINGLE || EPI == EPI_LAP_DUAL) {
-        __shared__ double wl[WIN_MAX_THREADS / 64];
         wloss = wave_sum(wloss);
         if (lane == 0) wl[wave] = wloss;
         __syncthreads();
         if (threadIdx.x == 0) {
             double t = 0.0;
             for (int w = 0; w < nwaves; ++w) t += wl[w];
-            a.loss_part[blockIdx.x] = t;
+            publish(a.loss_part + blockIdx.x, t);
         }
+        finish_loss(a, gridDim.x, wl, &last_flag);
     }
 }
 
@@ -772,54 +966,6 @@ __global__ __launch_bounds__(256) void lap_scale(int64_t m, int k, int64_t ldy, 
     }
 }
 
-// M1 = C (V^T Yn), M2 = C^T (U^T X2): the 3 x KP matrices of the rank-3 correction.  Launched with
-// split x 6 KP threads (split <= FINISH_SPLIT): the block partials of one column sum are dealt to `split`
-// threads (fixed assignment, eight independent chains each) and combined in a fixed order.
-constexpr int FINISH_SPLIT = 4;
-__global__ void lap_colsum_finish(int KP, int nparts, int split, bool dual, const float* __restrict__ colpart,
-                                  const double* __restrict__ coupling, float* __restrict__ M12) {
-    __shared__ double S[FINISH_SPLIT][6][SPARC_MAX_K];
-    const int e = threadIdx.x % (6 * KP), share = threadIdx.x / (6 * KP);
-    const int q = e / KP, col = e % KP;
-    const int ns = dual ? 6 : 3;
-    if (q < ns) {
-        double t[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // eight independent chains, fixed order
-        int b = share;
-        for (; b + 7 * split < nparts; b += 8 * split) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] += colpart[(static_cast<int64_t>(b + u * split) * 6 + q) * KP + col];
-        }
-        for (; b < nparts; b += split) t[0] += colpart[(static_cast<int64_t>(b) * 6 + q) * KP + col];
-        S[share][q][col] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
-    }
-    __syncthreads();
-    if (share == 0 && q < ns) {
-        double t = 0.0;
-        for (int b = 0; b < 3; ++b) {
-            const int src = q < 3 ? b : 3 + b;
-            double sum = S[0][src][col];
-            for (int h = 1; h < split; ++h) sum += S[h][src][col];
-            t += (q < 3 ? coupling[q * 3 + b] : coupling[b * 3 + (q - 3)]) * sum;
-        }
-        M12[q * KP + col] = static_cast<float>(t);
-    }
-    if (threadIdx.x < 9) M12[6 * KP + threadIdx.x] = static_cast<float>(coupling[threadIdx.x]);
-}
-
-__global__ __launch_bounds__(256) void loss_finish(int64_t n, const double* __restrict__ part, double scale,
-                                                   double* __restrict__ loss) {
-    __shared__ double sm[256];
-    double t = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 256) t += part[i];
-    sm[threadIdx.x] = t;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *loss = sm[0] * scale;
-}
-
 // ------------------------------------------------------------------ launch helpers
 // Optional timing of one kernel class with HIP events recorded on the launch stream.  One profiling
 // session per process at a time; the mutex only keeps concurrent launches from corrupting the table.
@@ -856,6 +1002,7 @@ int launch_rows(const SpmmArgs& a, hipStream_t stream) {
     const int64_t nb = (a.m + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
     if (nb <= 0) return SPARC_OK;
     if (nb > 0x7fffffffLL) return SPARC_ERR_ARG;
+    if (EPI == EPI_ADD_X0 && a.fin.colpart && nb < a.fin.kp) return SPARC_ERR_ARG;   // (the caller checks: fin_can_ride)
     hipLaunchKernelGGL((spmm_rows<LR, DUAL, EPI>), dim3(static_cast<unsigned>(nb)), dim3(256), 0, stream, a);
     SPARC_CHECK_LAUNCH();
     return SPARC_OK;
@@ -1110,6 +1257,9 @@ int lap_fwd_impl(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* c
     a.m = m; a.nnz = nnz; a.rowptr = rowptr; a.col = colidx; a.val = val; a.valT = valT ? valT : val;
     a.rowc = rowc; a.M12 = M12; a.loss_part = loss_part; a.gradY = gradY; a.ldy = ldy; a.k = k; a.kp = kp;
     a.inv_m = static_cast<float>(1.0 / static_cast<double>(m));
+    a.loss_out = loss;
+    a.loss_scale = 1.0 / static_cast<double>(m);
+    a.chain_slot = static_cast<int>(g_chain_next.fetch_add(1u, std::memory_order_relaxed) % CHAIN_SLOTS);
     int rcode = set_tiling(a, tiling, m, dual, kp);
     if (rcode) return rcode;
     const int64_t nparts = tiled ? tiling->ndesc : sparc_rows_blocks(m);
@@ -1122,17 +1272,24 @@ int lap_fwd_impl(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* c
 #define SPARC_SCALE(KP)                                                                                              \
     if (dual)                                                                                                        \
         hipLaunchKernelGGL((lap_scale<KP, true>), gs, bs, 0, stream, m, k, ldy, Y, rowc, X, hw, rw, plane, colpart,   \
-                           p.rows_per_block, a.rowpat);                                                                        \
+                           p.rows_per_block, a.rowpat);                                                               \
     else                                                                                                             \
         hipLaunchKernelGGL((lap_scale<KP, false>), gs, bs, 0, stream, m, k, ldy, Y, rowc, X, hw, rw, plane, colpart,  \
                            p.rows_per_block, a.rowpat);
     if (kp == 16) { SPARC_SCALE(16) } else if (kp == 32) { SPARC_SCALE(32) } else if (kp == 48) { SPARC_SCALE(48) } else { SPARC_SCALE(64) }
 #undef SPARC_SCALE
     SPARC_CHECK_LAUNCH();
-    const int split = min(FINISH_SPLIT, 1024 / (6 * kp));
-    hipLaunchKernelGGL(lap_colsum_finish, dim3(1), dim3(split * 6 * kp), 0, stream, kp, static_cast<int>(p.nscale), split, dual,
-                       colpart, coupling, M12);
-    SPARC_CHECK_LAUNCH();
+    ColsumFinish fin = {colpart, coupling, M12, kp, static_cast<int>(p.nscale), dual ? 1 : 0};
+    // rides with the first inner pass when that pass has a workgroup per column with enough waves for the six sums;
+    // the block kernel has no room for a passenger
+    const bool rides = !blocks && p.nscale <= 128 &&
+                       (tiled ? (tiling->ndesc >= kp && tiling->threads >= 6 * 64) : sparc_rows_blocks(m) >= kp);
+    if (rides) {
+        a.fin = fin;
+    } else {
+        hipLaunchKernelGGL(lap_colsum_finish, dim3(1), dim3(min(FINISH_SPLIT, 1024 / (6 * kp)) * 6 * kp), 0, stream, fin);
+        SPARC_CHECK_LAUNCH();
+    }
 
     a.X0 = X;
     // Horner: chain(X) = A (X + A (X + A X)).  With dense blocks a pass is two launches: the blocks' product
@@ -1149,6 +1306,7 @@ int lap_fwd_impl(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* c
             rcode = dual ? launch_dual<EPI_ADD_X0>(kp, a, stream) : launch_single<EPI_ADD_X0>(W, a, stream);
             if (rcode) return rcode;
         }
+        a.fin = ColsumFinish{};
         a.Xg = P1; a.out = P2;
         if (blocks) {
             bl.Xg = P1; bl.X0 = X; bl.out = P2;
@@ -1172,8 +1330,10 @@ int lap_fwd_impl(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* c
         rcode = dual ? launch_dual<EPI_LAP_DUAL>(kp, a, stream) : launch_single<EPI_LAP_SINGLE>(W, a, stream);
         if (rcode) return rcode;
     }
-    hipLaunchKernelGGL(loss_finish, dim3(1), dim3(256), 0, stream, nparts, loss_part, 1.0 / static_cast<double>(m), loss);
-    SPARC_CHECK_LAUNCH();
+    if (!tiled) {   // the windowed kernel's last workgroup has written the loss; the row kernel leaves partials
+        hipLaunchKernelGGL(loss_finish, dim3(1), dim3(256), 0, stream, nparts, loss_part, 1.0 / static_cast<double>(m), loss);
+        SPARC_CHECK_LAUNCH();
+    }
     return SPARC_OK;
 }
 }  // namespace

@@ -275,10 +275,10 @@ def test_bench_two_ranks_started_by_bench_itself():
     import json
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(SPARC_BENCH_BACKEND="gloo", SPARC_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scale", "0.01", "--steps", "4",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scale", "0.04", "--steps", "4",
                           "--warmup", "2", "--batches-per-rank", "2", "--no-cpu-baseline"], env=env, capture_output=True,
                          text=True, timeout=400)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-12000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout
     rec = json.loads(lines[0])

@@ -26,7 +26,7 @@ def spmm_asm(tmp_path_factory):
                                       os.path.join(ROOT, "sparc_amd", "csrc", "spmm.hip")], check=True, cwd=str(out.parent))
     text = out.read_text()
     kernels = {}
-    for m in re.finditer(r"^(_Z\w*spmm_win\w*):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
+    for m in re.finditer(r"^(_Z\w*spmm_win\w*):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M):   # (a kernel may end in several places)
         body = [l.split(";")[0].strip() for l in m.group(2).splitlines()]     # drop comments
         kernels[m.group(1)] = [l for l in body if l and not l.startswith(".") and not l.endswith(":")]
     assert len(kernels) >= 16, "spmm_win instantiations not found in the assembly"
@@ -87,8 +87,10 @@ def test_no_dpp_read_within_two_wait_states_of_a_vector_write(spmm_asm):
 def test_lds_staging_is_waited_for_before_the_barrier(spmm_asm):
     _, kernels = spmm_asm
     for name, ins in kernels.items():
-        bar = next(i for i, l in enumerate(ins) if l.startswith("s_barrier"))
-        last_dma = max(i for i, l in enumerate(ins[:bar]) if "global_load_lds" in l)
+        # (the pass that carries the column-sum finish holds that workgroup's barrier too: the barrier that publishes
+        # the window is the first one after the staging copies)
+        last_dma = max(i for i, l in enumerate(ins) if "global_load_lds" in l)
+        bar = next(i for i, l in enumerate(ins) if i > last_dma and l.startswith("s_barrier"))
         between = ins[last_dma:bar]
         assert any(re.match(r"s_waitcnt vmcnt\(0\)", l) for l in between), name
 
@@ -114,7 +116,7 @@ def test_block_kernel_staging_and_registers(tmp_path):
                                       os.path.join(ROOT, "sparc_amd", "csrc", "blocks.hip")], check=True, cwd=str(tmp_path))
     text = out.read_text()
     found = 0
-    for m in re.finditer(r"^(_Z\w*dense_blocks\w*):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
+    for m in re.finditer(r"^(_Z\w*dense_blocks\w*):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M):   # (the staging wait's trap ends the kernel too)
         ins = [l.split(";")[0].strip() for l in m.group(2).splitlines()]
         ins = [l for l in ins if l and not l.startswith(".") and not l.endswith(":")]
         found += 1
