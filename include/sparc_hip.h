@@ -195,6 +195,20 @@ int sparc_blocks_spmm(int64_t m, int width, const sparc_blocks_t* blocks, const 
 int sparc_spmm(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* colidx,
                const float* val, int width, const float* X, const float* X0, float* Z,
                const sparc_tiling_t* tiling, sparc_stream_t stream);
+/* Z = A X (+ X0) for a matrix with hub rows: every row of more than split_above (>= 64) stored entries is cut into
+ * chunks that get a wavefront each, and the chunks' partial sums are added in chunk order (with the row's X0), so
+ * a hub row no longer keeps one wavefront busy long after the rest of the launch has drained, and the result does
+ * not depend on the schedule.  The reference has no sparse product at all (it multiplies the dense m x m matrices,
+ * src/SpectralTrainer.py:289); this is the whole-graph product of BASELINE config 5 (R-MAT, 10 M nodes).
+ * The caller supplies the plan, all device arrays: long_row[nlong], the rows above the limit; the chunks of
+ * long_row[i] are c in [long_first[i], long_first[i + 1]) (long_first has nlong + 1 entries, long_first[nlong] ==
+ * nchunks) and chunk c covers the stored entries [chunk_begin[c], chunk_end[c]), which together are exactly the
+ * row's entries in order; partial is scratch for nchunks * width floats.  X0 may be Z (in-place accumulation over
+ * column blocks).  width: 16, 32, 64 or 128.  sparc_amd.graph.RowSplit builds the plan from rowptr. */
+int sparc_spmm_split(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* colidx, const float* val,
+                     int width, const float* X, const float* X0, float* Z, int64_t split_above, int64_t nlong,
+                     const int32_t* long_row, const int64_t* long_first, int64_t nchunks,
+                     const int64_t* chunk_begin, const int64_t* chunk_end, float* partial, sparc_stream_t stream);
 
 /* Measurement aid (no counterpart in the reference): between begin and end, every launch of the
  * row-gather kernel with the given epilogue (1 = the two inner passes of sparc_lap_fwd and

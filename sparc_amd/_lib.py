@@ -52,6 +52,7 @@ _SIGS = {
     "sparc_lap_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "sparc_lap_fwd": (c_int, [c_int64, c_int64, P, P, P, P, P, P, c_int, c_int64, P, P, P, P, P, c_size_t, P]),
     "sparc_spmm": (c_int, [c_int64, c_int64, P, P, P, c_int, P, P, P, P, P]),
+    "sparc_spmm_split": (c_int, [c_int64, c_int64, P, P, P, c_int, P, P, P, c_int64, c_int64, P, P, c_int64, P, P, P, P]),
     "sparc_lap_fwd_blocks": (c_int, [c_int64, c_int64, P, P, P, P, P, P, c_int, c_int64, P, P, P, P, P, c_size_t, P]),
     "sparc_blocks_spmm": (c_int, [c_int64, c_int, P, P, P, P, P]),
     "sparc_profile_begin": (c_int, [c_int, c_int]),

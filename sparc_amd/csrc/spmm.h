@@ -33,6 +33,8 @@ struct SpmmArgs {
     float* out;       // [m][W]
     const float* addend;  // row kernel: [m][W] added to the row's product before the epilogue (the dense-block part), or null
     int skip_entries;     // row kernel: the addend is the whole product, no entry is gathered (epilogue only)
+    int interleave_rows;  // row kernel, plain products: workgroup b takes rows 4 b .. 4 b + 3 (consecutive workgroups run on different XCDs)
+    int64_t split_above;  // row kernel, plain products: rows of more entries are left to spmm_chunks / spmm_merge (0: none)
     // Laplacian epilogues
     const float* rowc;  // [m][SPARC_ROWC]
     const float* M12;   // [6][KP]

@@ -393,20 +393,16 @@ __device__ __forceinline__ void gather_rows(float4& acc, const int c, const floa
     }
 }
 
-// One row, gathered from global memory by the whole wave.
-template <int LR, bool DUAL, int EPI>
-__device__ __forceinline__ void wave_row_global(const SpmmArgs& a, const int64_t row, const int lane, double& wloss) {
-    constexpr int W = LR * 4;       // floats per row of X
+// The stored entries [p0, p1) of one row, gathered from global memory by the whole wave: lane (g, lr) ends up
+// with the partial sum of its group's entries over its four columns (the G groups still to be added).
+// FL: the sweeps of the affinity preparation multiply operands whose rows are mostly zero: a byte per operand row
+// says whether it holds anything, zero rows are neither stored nor read (the sums are the same bit for bit);
+// any_live (wave-uniform) tells whether any entry pointed at a row that holds something.
+template <int LR, bool DUAL, bool FL>
+__device__ __forceinline__ float4 gather_range(const SpmmArgs& a, const int64_t p0, const int64_t p1, const int lane, bool& any_live) {
     constexpr int G = 64 / LR;      // rows of X gathered per wave instruction
-    constexpr int HALF = LR / 2;
     const int g = lane / LR, lr = lane % LR;
-    const int64_t p0 = a.skip_entries ? 0 : a.rowptr[row], p1 = a.skip_entries ? 0 : a.rowptr[row + 1];
-    const RowPre<4> pre = row_preload<4, EPI>(a, row, a.X0 ? a.X0 + row * W + lr * 4 : nullptr);
-    // the sweeps of the affinity preparation multiply operands whose rows are mostly zero: a byte per operand row
-    // says whether it holds anything, zero rows are neither stored nor read (the sums are the same bit for bit)
-    constexpr bool FL = EPI == EPI_ADD_IDENT || EPI == EPI_PREP_ACC;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    bool any_live = false;  // wave-uniform
     for (int64_t p = p0; p < p1; p += 64) {
         const int cnt = static_cast<int>(min(static_cast<int64_t>(64), p1 - p));
         int c = 0, f = 0;
@@ -443,7 +439,11 @@ __device__ __forceinline__ void wave_row_global(const SpmmArgs& a, const int64_t
         if (it + 2 <= iters) { gather_rows<LR, DUAL, 2>(acc, c, v, vt, it, g, lr, a.Xg); it += 2; }
         if (it < iters) gather_rows<LR, DUAL, 1>(acc, c, v, vt, it, g, lr, a.Xg);
     }
-    if (EPI == EPI_PREP_ACC && !any_live) return;  // a zero row of S[:, J] adds nothing to the statistics
+    return acc;
+}
+
+template <int LR>
+__device__ __forceinline__ void merge_groups(float4& acc) {   // the sum over the wave's G groups, in every lane
 #pragma unroll
     for (int off = LR; off < 64; off <<= 1) {
         acc.x += __shfl_xor(acc.x, off);
@@ -451,6 +451,23 @@ __device__ __forceinline__ void wave_row_global(const SpmmArgs& a, const int64_t
         acc.z += __shfl_xor(acc.z, off);
         acc.w += __shfl_xor(acc.w, off);
     }
+}
+
+// One row, gathered from global memory by the whole wave.
+template <int LR, bool DUAL, int EPI>
+__device__ __forceinline__ void wave_row_global(const SpmmArgs& a, const int64_t row, const int lane, double& wloss) {
+    constexpr int W = LR * 4;       // floats per row of X
+    constexpr int HALF = LR / 2;
+    const int g = lane / LR, lr = lane % LR;
+    const int64_t p0 = a.skip_entries ? 0 : a.rowptr[row], p1 = a.skip_entries ? 0 : a.rowptr[row + 1];
+    // a split product: the rows above the limit are cut into chunks that have waves of their own (spmm_chunks)
+    if ((EPI == EPI_STORE || EPI == EPI_ADD_X0) && a.split_above > 0 && p1 - p0 > a.split_above) return;
+    const RowPre<4> pre = row_preload<4, EPI>(a, row, a.X0 ? a.X0 + row * W + lr * 4 : nullptr);
+    constexpr bool FL = EPI == EPI_ADD_IDENT || EPI == EPI_PREP_ACC;
+    bool any_live = false;  // wave-uniform
+    float4 acc = gather_range<LR, DUAL, FL>(a, p0, p1, lane, any_live);
+    if (EPI == EPI_PREP_ACC && !any_live) return;  // a zero row of S[:, J] adds nothing to the statistics
+    merge_groups<LR>(acc);
     const bool right = DUAL && lr >= HALF;
     const int cl = (DUAL ? (lr % HALF) : lr) * 4;
     const LapConst<4> lc = lap_const<4, EPI>(a, cl, right);
@@ -463,10 +480,56 @@ __device__ __forceinline__ void wave_row_global(const SpmmArgs& a, const int64_t
                                a.out ? a.out + row * W + lr * 4 : nullptr, a.col0 + lr * 4, wloss);
 }
 
+// ------------------------------------------------------------------ long rows in chunks
+// A graph with hub rows (R-MAT: rows of several hundred thousand entries among rows of a few dozen) keeps one
+// wave busy with a hub for milliseconds after every other wave has finished.  A split product cuts every row
+// above a limit into chunks of at most that many entries: one wave per chunk writes the chunk's partial sum
+// (spmm_chunks), and the chunks of a row are added in their order, with the row's own operand, by spmm_merge:
+// the result does not depend on which wave ran when.  The row kernel skips those rows (SpmmArgs::split_above).
+template <int LR>
+__global__ __launch_bounds__(256) void spmm_chunks(const SpmmArgs a, const int64_t* __restrict__ chunk_begin,
+                                                   const int64_t* __restrict__ chunk_end, int64_t nchunks,
+                                                   float* __restrict__ partial) {
+    constexpr int W = LR * 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t id = static_cast<int64_t>(blockIdx.x) * 4 + wave;   // neighbouring chunks go to different XCDs
+    if (id >= nchunks) return;
+    bool any_live = false;
+    float4 acc = gather_range<LR, false, false>(a, chunk_begin[id], chunk_end[id], lane, any_live);
+    merge_groups<LR>(acc);
+    if (lane < LR) *reinterpret_cast<float4*>(partial + id * W + lane * 4) = acc;
+}
+
+// thread = (long row, four columns): its chunks' partial sums in chunk order, plus the own-row operand
+template <int LR>
+__global__ __launch_bounds__(256) void spmm_merge(const SpmmArgs a, const int32_t* __restrict__ long_row,
+                                                  const int64_t* __restrict__ long_first, int64_t nlong,
+                                                  const float* __restrict__ partial) {
+    constexpr int W = LR * 4;
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t i = t / LR;
+    const int lr = static_cast<int>(t % LR);
+    if (i >= nlong) return;
+    const int64_t row = long_row[i];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t c = long_first[i]; c < long_first[i + 1]; ++c) {
+        const float4 v = *reinterpret_cast<const float4*>(partial + c * W + lr * 4);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    if (a.X0) {
+        const float4 v = *reinterpret_cast<const float4*>(a.X0 + row * W + lr * 4);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(a.out + row * W + lr * 4) = acc;
+}
+
 template <int LR, bool DUAL, int EPI>
 __global__ __launch_bounds__(256) void spmm_rows(const SpmmArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    // neighbouring rows meet in one XCD's L2 (cluster batches), unless the caller wants them dealt to all XCDs in
+    // turn: rows ordered by degree would otherwise hand one XCD all the work
+    const int64_t blk = ((EPI == EPI_STORE || EPI == EPI_ADD_X0) && a.interleave_rows) ? static_cast<int64_t>(blockIdx.x)
+                                                                                         : xcd_contiguous_block(blockIdx.x, gridDim.x);
     if (EPI == EPI_ADD_X0) {   // this workgroup's share of the column-sum finish, out of the way before the rows
         __shared__ double fs[6];
         FinishShare<2> fin;
@@ -1174,6 +1237,48 @@ extern "C" int sparc_spmm(int64_t m, int64_t nnz, const int64_t* rowptr, const i
     if (tiling && (tiling->kp != width || width != 16 * tiling->vec)) return SPARC_ERR_ARG;
     const int rc = set_tiling(a, tiling, m, false, width);
     if (rc) return rc;
+    return sparc_spmm_launch(X0 ? EPI_ADD_X0 : EPI_STORE, width, a, stream);
+}
+
+namespace {
+template <int LR>
+int launch_split(const SpmmArgs& a, int64_t nlong, const int32_t* long_row, const int64_t* long_first, int64_t nchunks,
+                 const int64_t* chunk_begin, const int64_t* chunk_end, float* partial, hipStream_t stream) {
+    const int64_t cb = (nchunks + 3) / 4, mb = (nlong * LR + 255) / 256;
+    if (cb > 0x7fffffffLL || mb > 0x7fffffffLL) return SPARC_ERR_ARG;
+    hipLaunchKernelGGL((spmm_chunks<LR>), dim3(static_cast<unsigned>(cb)), dim3(256), 0, stream, a, chunk_begin, chunk_end, nchunks, partial);
+    SPARC_CHECK_LAUNCH();
+    hipLaunchKernelGGL((spmm_merge<LR>), dim3(static_cast<unsigned>(mb)), dim3(256), 0, stream, a, long_row, long_first, nlong, partial);
+    SPARC_CHECK_LAUNCH();
+    return SPARC_OK;
+}
+}  // namespace
+
+extern "C" int sparc_spmm_split(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* colidx, const float* val,
+                                int width, const float* X, const float* X0, float* Z, int64_t split_above, int64_t nlong,
+                                const int32_t* long_row, const int64_t* long_first, int64_t nchunks,
+                                const int64_t* chunk_begin, const int64_t* chunk_end, float* partial, sparc_stream_t stream) {
+    if (m < 0 || nnz < 0 || !rowptr || (nnz > 0 && (!colidx || !val)) || !X || !Z || split_above < 64 || nlong < 0 || nchunks < nlong ||
+        (nlong > 0 && (!long_row || !long_first || !chunk_begin || !chunk_end || !partial)) ||
+        (width != 16 && width != 32 && width != 64 && width != 128))
+        return SPARC_ERR_ARG;
+    SpmmArgs a = {};
+    a.m = m; a.nnz = nnz; a.rowptr = rowptr; a.col = colidx; a.val = val; a.valT = val;
+    a.Xg = X; a.X0 = X0; a.out = Z;
+    a.kp = width;
+    a.split_above = split_above;
+    a.interleave_rows = 1;
+    // the hub rows first: their chunks are the long poles, the short rows fill in behind them
+    if (nlong > 0) {
+        int rc = SPARC_ERR_ARG;
+        switch (width) {
+            case 16: rc = launch_split<4>(a, nlong, long_row, long_first, nchunks, chunk_begin, chunk_end, partial, stream); break;
+            case 32: rc = launch_split<8>(a, nlong, long_row, long_first, nchunks, chunk_begin, chunk_end, partial, stream); break;
+            case 64: rc = launch_split<16>(a, nlong, long_row, long_first, nchunks, chunk_begin, chunk_end, partial, stream); break;
+            case 128: rc = launch_split<32>(a, nlong, long_row, long_first, nchunks, chunk_begin, chunk_end, partial, stream); break;
+        }
+        if (rc) return rc;
+    }
     return sparc_spmm_launch(X0 ? EPI_ADD_X0 : EPI_STORE, width, a, stream);
 }
 

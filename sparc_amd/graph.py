@@ -664,3 +664,52 @@ class ClusterBatch:
         if self.valT is not None:
             t.append(self.valT)
         return sum(x.numel() * x.element_size() for x in t)
+
+
+class RowSplit:
+    """Plan of a split product (sparc_spmm_split) for a CSR pattern with hub rows: the rows of more than `limit`
+    stored entries, cut into chunks of at most `limit` entries.  Built once per graph from its row pointers, on
+    the device."""
+
+    def __init__(self, rowptr: torch.Tensor, limit: int = 2048):
+        if limit < 64:
+            raise ValueError("the row limit of a split product is at least one wavefront of entries (64)")
+        self.limit = int(limit)
+        dev = rowptr.device
+        deg = rowptr[1:] - rowptr[:-1]
+        self.long_row = torch.nonzero(deg > limit).flatten().to(torch.int32)
+        self.nlong = int(self.long_row.numel())
+        ldeg = deg[self.long_row.long()]
+        per = torch.div(ldeg + (limit - 1), limit, rounding_mode="floor")          # chunks of every long row
+        self.long_first = torch.zeros(self.nlong + 1, dtype=torch.int64, device=dev)
+        self.long_first[1:] = torch.cumsum(per, 0)
+        self.nchunks = int(self.long_first[-1]) if self.nlong else 0
+        owner = torch.repeat_interleave(torch.arange(self.nlong, device=dev), per, output_size=self.nchunks)
+        within = torch.arange(self.nchunks, device=dev, dtype=torch.int64) - self.long_first[owner]
+        start = rowptr[self.long_row.long()][owner]
+        # equal chunks (the last of a row no shorter than the others by more than one entry per chunk)
+        size = torch.div(ldeg[owner] + per[owner] - 1, per[owner], rounding_mode="floor")
+        self.chunk_begin = (start + within * size).contiguous()
+        self.chunk_end = torch.minimum(self.chunk_begin + size, rowptr[self.long_row.long() + 1][owner]).contiguous()
+        self._partial = None
+
+    def partial(self, width: int) -> torch.Tensor:
+        n = max(self.nchunks, 1) * width
+        if self._partial is None or self._partial.numel() < n:
+            self._partial = torch.empty(n, dtype=torch.float32, device=self.long_first.device)
+        return self._partial
+
+
+def spmm_split(plan: RowSplit, m: int, rowptr: torch.Tensor, colidx: torch.Tensor, val: torch.Tensor, X: torch.Tensor,
+               add: torch.Tensor | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
+    """Z = A X (+ add) with the long rows of the plan in chunks; add may be out itself."""
+    require_gpu(X.device)
+    X = X.contiguous()
+    Z = torch.empty_like(X) if out is None else out
+    width = int(X.shape[1])
+    with torch.cuda.device(X.device):
+        check(lib.sparc_spmm_split(m, int(colidx.numel()), _ptr(rowptr), _ptr(colidx), _ptr(val), width, _ptr(X), _ptr(add), _ptr(Z),
+                                   plan.limit, plan.nlong, _ptr(plan.long_row), _ptr(plan.long_first), plan.nchunks,
+                                   _ptr(plan.chunk_begin), _ptr(plan.chunk_end), _ptr(plan.partial(width)), _stream()),
+              "sparc_spmm_split")
+    return Z

@@ -82,3 +82,55 @@ def test_product_accumulated_in_place_over_column_blocks():
     scale = np.maximum(np.abs(ref).max(axis=1, keepdims=True), 1e-3)
     assert (np.abs(Z.cpu().numpy() - ref) / scale).max() < 1e-5
     assert np.all(Z.cpu().numpy()[100:140] == 0) and empty_blocks == 1
+
+
+@pytest.mark.parametrize("width", [64, 128, 16])
+def test_split_product_with_hub_rows_matches_scipy(width):
+    """sparc_spmm_split: a graph whose first node is linked to 120 000 others (a row of more than 100 k entries, 59
+    chunks) among R-MAT rows, several rows just above and just below the limit, through the C ABI against SciPy; the
+    accumulation in place (X0 = Z); and the same bits on every run (the chunks are added in their order)."""
+    from sparc_amd import synth
+    from sparc_amd._lib import lib
+    from sparc_amd.graph import RowSplit, spmm_split
+    dev = torch.device("cuda:0")
+    n, e = 150000, 600000
+    rowptr, colidx = synth.rmat_graph(n, e, dev, seed=7)
+    A = sp.csr_matrix((np.ones(colidx.numel(), np.float32), colidx.cpu().numpy(), rowptr.cpu().numpy()), shape=(n, n)).tolil()
+    rng = np.random.default_rng(0)
+    hub = rng.choice(np.arange(1, n), size=120000, replace=False)
+    A[0, hub] = 1.0
+    A[hub, 0] = 1.0
+    for r, d in ((5, 2048), (6, 2049), (7, 4097), (8, 2047)):       # at, just above (two chunks), three chunks, below
+        A[r, :] = 0
+        A[r, rng.choice(n, size=d, replace=False)] = 1.0
+    A = A.tocsr()
+    A.sort_indices()
+    A.data = (rng.random(A.nnz) + 0.5).astype(np.float32)
+    deg = np.diff(A.indptr)
+    assert deg[0] > 100000 and deg[5] == 2048 and deg[6] == 2049 and deg[7] == 4097
+    rp = torch.from_numpy(A.indptr.astype(np.int64)).to(dev)
+    ci = torch.from_numpy(A.indices.astype(np.int32)).to(dev)
+    val = torch.from_numpy(A.data).to(dev)
+    plan = RowSplit(rp, limit=2048)
+    assert plan.nlong == int((deg > 2048).sum()) and 0 in plan.long_row.cpu().numpy() and 5 not in plan.long_row.cpu().numpy()
+    per_row = np.diff(plan.long_first.cpu().numpy())
+    assert per_row[0] == -(-deg[0] // 2048) and plan.nchunks == per_row.sum()
+    cb, ce = plan.chunk_begin.cpu().numpy(), plan.chunk_end.cpu().numpy()
+    assert (ce - cb).max() <= 2048 and (ce - cb).min() >= 1
+    for i, r in enumerate(plan.long_row.cpu().numpy()):             # the chunks of a row tile its entries in order
+        a, b = plan.long_first[i].item(), plan.long_first[i + 1].item()
+        assert cb[a] == A.indptr[r] and ce[b - 1] == A.indptr[r + 1] and np.array_equal(cb[a + 1:b], ce[a:b - 1])
+    X = torch.randn(n, width, device=dev)
+    ref = A.astype(np.float64) @ X.cpu().numpy().astype(np.float64)
+    scale = np.maximum(np.abs(ref).max(axis=1, keepdims=True), 1e-3)
+    Z = spmm_split(plan, n, rp, ci, val, X)
+    assert (np.abs(Z.cpu().numpy() - ref) / scale).max() < 1e-5
+    assert torch.equal(Z, spmm_split(plan, n, rp, ci, val, X))      # the same bits, whatever the schedule was
+    Zu = _spmm(lib, n, rp, ci, val, X)                              # the unsplit product: one wave per row
+    assert (np.abs(Zu.cpu().numpy() - ref) / scale).max() < 1e-5
+    acc = X.clone()                                                 # in place: acc = acc + A X
+    spmm_split(plan, n, rp, ci, val, X, add=acc, out=acc)
+    assert (np.abs(acc.cpu().numpy() - (ref + X.cpu().numpy())) / np.maximum(scale, 1.0)).max() < 1e-5
+    none = RowSplit(rp, limit=1 << 20)                              # no row above the limit: the plain row kernel
+    assert none.nlong == 0 and none.nchunks == 0
+    assert torch.equal(spmm_split(none, n, rp, ci, val, X), Zu)

@@ -10,7 +10,7 @@ import csv, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/stress_pmc_*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "spmm_rows" in r["Kernel_Name"] or "spmm_win" in r["Kernel_Name"]:
+        if any(t in r["Kernel_Name"] for t in ("spmm_rows", "spmm_win", "spmm_chunks", "spmm_merge")):
             acc[r["Kernel_Name"][:50]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in acc.items():
     line = {c: sum(v) / len(v) for c, v in cs.items()}

@@ -5,7 +5,8 @@ natural and in degree order, and the cluster-ordered Amazon2M-shape planted-clus
 kernel and with the windowed kernel.  One launch per product (sparc_spmm); prints one JSON line per case
 with the algorithmic bytes, the kernel time (HIP events on the launch stream) and the fraction of the
 8 TB/s HBM peak.  Cases: python tools/spmm_stress.py [rmat] [rmat-blocked[=N]] [rmat-degree] [amazon2m] [amazon2m-windowed]
-(RMAT_NODES / RMAT_EDGES shrink the R-MAT graph)."""
+rmat-split[=LIMIT] / rmat-degree-split[=LIMIT]: the same products with every row above LIMIT entries cut into
+chunks (sparc_spmm_split).  (RMAT_NODES / RMAT_EDGES shrink the R-MAT graph)."""
 import ctypes
 import json
 import os
@@ -24,14 +25,24 @@ HBM_PEAK_GBS = 8000.0
 P = lambda t: ctypes.c_void_p(t.data_ptr())
 
 
-def run(name, n, rowptr, colidx, width=64, reps=5, tiling=None, kernel="spmm_rows"):
+def run(name, n, rowptr, colidx, width=64, reps=5, tiling=None, kernel="spmm_rows", split=0):
     nnz = int(colidx.numel())
     val = torch.ones(nnz, dtype=torch.float32, device=dev)
     X = torch.randn(n, width, device=dev)
     Z = torch.empty_like(X)
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    plan = None
+    if split:
+        from sparc_amd.graph import RowSplit, spmm_split
+        plan = RowSplit(rowptr, limit=split)
+        deg = rowptr[1:] - rowptr[:-1]
+        kernel = (f"spmm_rows + spmm_chunks / spmm_merge: {plan.nlong} rows above {split} entries (longest {int(deg.max())}) "
+                  f"in {plan.nchunks} chunks holding {int(deg[plan.long_row.long()].sum())} entries")
 
     def launch():
+        if plan is not None:
+            spmm_split(plan, n, rowptr, colidx, val, X, out=Z)
+            return
         check(lib.sparc_spmm(n, nnz, P(rowptr), P(colidx), P(val), width, P(X), None, P(Z),
                              ctypes.byref(tiling) if tiling is not None else None, stream), "sparc_spmm")
 
@@ -58,6 +69,9 @@ def run(name, n, rowptr, colidx, width=64, reps=5, tiling=None, kernel="spmm_row
            "algorithmic_bytes": alg, "achieved_GBps": alg / ms / 1e6, "frac_of_hbm_peak": alg / ms / 1e6 / HBM_PEAK_GBS,
            "gathered_row_GBps": nnz * width * 4 / ms / 1e6, "GFLOPs": 2.0 * nnz * width / ms / 1e6,
            "max_rel_err_sampled_rows": worst}
+    if "decreasing degree" in name:   # how much of the gather traffic the hottest operand rows carry (they are the first rows)
+        for top in (16384, 131072, 1048576):
+            out[f"share_of_entries_pointing_at_the_{top}_rows_of_highest_degree"] = float((colidx < top).sum()) / nnz
     print(json.dumps(out), flush=True)
     return out
 
@@ -136,20 +150,28 @@ def main():
         rowptr, colidx = synth.rmat_graph(n, e, dev)
         torch.cuda.synchronize()
         print(f"[stress] R-MAT graph ({n} nodes, {e} undirected edges) built in {time.perf_counter() - t0:.1f}s", file=sys.stderr, flush=True)
+        tag = f"R-MAT {n / 1e6:g}M / {2 * e / 1e6:g}M"
         if "rmat" in which:
-            run("R-MAT 10M / 500M, natural order", n, rowptr, colidx)
+            run(f"{tag}, natural order", n, rowptr, colidx)
+        for w in which:
+            if w.startswith("rmat-split"):        # rmat-split or rmat-split=<row limit>
+                run(f"{tag}, natural order", n, rowptr, colidx, split=int(w.split("=")[1]) if "=" in w else 2048)
         for w in which:
             if w.startswith("rmat-blocked"):      # rmat-blocked or rmat-blocked=<source nodes per block>
                 br = int(w.split("=")[1]) if "=" in w else 1 << 19
-                run_blocked("R-MAT 10M / 500M, natural order", n, rowptr, colidx, br)
+                run_blocked(f"{tag}, natural order", n, rowptr, colidx, br)
                 torch.cuda.empty_cache()
-        if "rmat-degree" in which:
+        if any(w.startswith("rmat-degree") for w in which):
             t0 = time.perf_counter()
             rp2, ci2, _ = synth.degree_order(rowptr, colidx)
             torch.cuda.synchronize()
             print(f"[stress] degree ordering in {time.perf_counter() - t0:.1f}s", file=sys.stderr, flush=True)
             del rowptr, colidx
-            run("R-MAT 10M / 500M, nodes relabelled by decreasing degree", n, rp2, ci2)
+            if "rmat-degree" in which:
+                run(f"{tag}, nodes relabelled by decreasing degree", n, rp2, ci2)
+            for w in which:
+                if w.startswith("rmat-degree-split"):
+                    run(f"{tag}, nodes relabelled by decreasing degree", n, rp2, ci2, split=int(w.split("=")[1]) if "=" in w else 2048)
             del rp2, ci2
         torch.cuda.empty_cache()
     if "amazon2m" in which or "amazon2m-windowed" in which:
