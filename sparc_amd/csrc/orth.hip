@@ -169,12 +169,59 @@ __device__ __forceinline__ double fast_rcp(const double x) {
 
 constexpr int KLD = SPARC_MAX_K + 1;  // leading dimension of the k x k LDS images (bank-conflict free columns)
 
+// C = scale * op(A) op(B) for k x k matrices in LDS (row-major images of SPARC_MAX_K rows, leading dimension KLD,
+// ZERO beyond k up to the next multiple of 16) on the f64 matrix cores: wave w of the workgroup's four takes the
+// 16 x 16 tiles w, w + 4, ... of the result and walks the inner dimension four at a time (v_mfma_f64_16x16x4:
+// lane l feeds opA[16 ti + (l & 15)][kk + (l >> 4)] and opB[kk + (l >> 4)][16 tj + (l & 15)]; result register q of
+// lane l is C[16 ti + (l >> 4) + 4 q][16 tj + (l & 15)]).  Whole tiles are written, so C is zero beyond k too.
+// C may not alias A or B.  Ends with a barrier.
+__device__ void mm_kk(int k, const double* A, bool ta, const double* B, bool tb, double* C, double scale) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int nt = (k + 15) / 16, n4 = nt * 4;   // inner steps of four (the images are zero up to 16 nt)
+    for (int t = wave; t < nt * nt; t += nwaves) {
+        const int ti = t / nt, tj = t % nt;
+        const int ar = 16 * ti + li, bc = 16 * tj + li;
+        // all operands of the tile are requested before the first product; two accumulators in turn
+        double av[16], bv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            av[i] = bv[i] = 0.0;
+            if (i < n4) {
+                const int l = 4 * i + lk;
+                av[i] = ta ? A[l * KLD + ar] : A[ar * KLD + l];
+                bv[i] = tb ? B[bc * KLD + l] : B[l * KLD + bc];
+            }
+        }
+        double4_t acc0 = double4_t{0.0, 0.0, 0.0, 0.0}, acc1 = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+            if (i < n4) {
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[i], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i + 1], bv[i + 1], acc1, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) C[(16 * ti + lk + 4 * q) * KLD + bc] = scale * (acc0[q] + acc1[q]);
+    }
+    __syncthreads();
+}
+
+// Zero the part of a k x k LDS image that mm_kk may read: rows and columns up to the next multiple of 16.
+__device__ __forceinline__ void zero_image(double* M, int k) {
+    const int kp = (k + 15) / 16 * 16;
+    for (int e = threadIdx.x; e < kp * kp; e += blockDim.x) M[(e / kp) * KLD + e % kp] = 0.0;
+}
+
 constexpr int OW_THREADS = 1024;
 
-// Single workgroup of 16 waves; every phase is bound by LDS latency, so the trailing updates give each
-// thread at most 2 x 2 elements, fully unrolled.  LDS images (padded leading dimension): R (Gram, then
-// its Cholesky factor, upper), X = R^-1, T (top rows of Yt), Q (scaled pivot rows during the
-// factorisation, then Yt[top] X and its sign-tracking LU).
+// Single workgroup of 16 waves; the two factorisations are bound by LDS latency and the barrier of every column,
+// so their trailing updates give each thread at most 2 x 2 elements, fully unrolled; the inverse of the factor and
+// the k x k products run on the f64 matrix cores (mm_kk).  LDS images (padded leading dimension): R (Gram, then
+// its Cholesky factor, upper), X = R^-1, T (top rows of Yt), Q (scaled pivot rows during the factorisation, then
+// Yt[top] X and its sign-tracking LU).  (Four waves with the trailing matrix in registers, one barrier per column
+// as well: 83 us against 63 us at k = 47; a column costs 1200-1450 cycles either way: the barrier, two LDS round
+// trips and the reciprocal square root chain, not the arithmetic.)
 __global__ __launch_bounds__(OW_THREADS) void orth_weights_kernel(int64_t m, int k, const double* __restrict__ G,
                                                                   const float* __restrict__ Yt, int64_t ld,
                                                                   const int32_t* __restrict__ top_idx, int mode,
@@ -190,16 +237,10 @@ __global__ __launch_bounds__(OW_THREADS) void orth_weights_kernel(int64_t m, int
     const int tid = threadIdx.x;
     const int ty = tid >> 5, tx = tid & 31;  // 32 x 32 thread grid over the trailing matrix
     if (tid == 0) bad = 0;
-    for (int e = tid; e < k * k; e += OW_THREADS) {
-        const int i = e / k, j = e % k;
-        R[i * KLD + j] = G[e];
-        double y = 0.0;
-        if (mode == 0) {
-            const int64_t row = top_idx ? top_idx[i] : i;
-            if (row < m) y = static_cast<double>(Yt[row * ld + j]);
-        }
-        T[i * KLD + j] = y;  // top rows of Yt
-    }
+    zero_image(R, k);   // the products on the matrix cores read whole 16 x 16 tiles: zero beyond k
+    zero_image(X, k);
+    __syncthreads();
+    for (int e = tid; e < k * k; e += OW_THREADS) R[(e / k) * KLD + e % k] = G[e];
     __syncthreads();
 
     // Cholesky, upper: G = R^T R, ONE barrier per column.  The working matrix R keeps the unscaled Schur
@@ -253,57 +294,59 @@ __global__ __launch_bounds__(OW_THREADS) void orth_weights_kernel(int64_t m, int
     }
     __syncthreads();
 
-    // X = R^-1 (upper): column c by back substitution on the 16 lanes of group c; lane r keeps the entries
-    // X[l][c], l = r (mod 16), in registers, so the solve itself needs no barrier
-    if (tid < k) sg[tid] = fast_rcp(R[tid * KLD + tid]);   // reciprocal diagonal, borrowed from the sign array
+    // X = R^-1.  With D the diagonal 16 x 16 blocks of R and N = D^-1 R - I (strictly block upper triangular, so
+    // N^4 = 0 for k <= 64):  R^-1 = (I + N)^-1 D^-1 = (I - N) (I + N^2) D^-1.
+    // D^-1: wave b inverts block b, lane c < 16 its column c by back substitution with the column in registers (the
+    // entries of R it needs are the same for all lanes: LDS broadcasts); the rest are four products on the matrix
+    // cores.  Rows beyond k are given a unit diagonal so that the blocks stay regular.  The factor itself is
+    // written out first: its image is reused.
+    const int kp = (k + 15) / 16 * 16;
+    for (int e = tid; e < k * k; e += OW_THREADS) Rc_out[e] = R[(e / k) * KLD + e % k];
+    if (tid >= k && tid < kp) R[tid * KLD + tid] = 1.0;
+    __syncthreads();
+    if (tid < kp) sg[tid] = fast_rcp(R[tid * KLD + tid]);   // reciprocal diagonal, borrowed from the sign array
     __syncthreads();
     {
-        const int c = tid >> 4, r = tid & 15;
-        double xr[4] = {0.0, 0.0, 0.0, 0.0};   // X[r + 16 q][c]
-        if (c < k) {
-            for (int i = c; i >= 0; --i) {
-                double t = 0.0;
+        const int lane = tid & 63, blk = tid >> 6;
+        if (16 * blk < kp && lane < 16) {
+            const int b0 = 16 * blk, c = lane;
+            double x[16];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int l = r + 16 * q;
-                    if (l > i && l <= c) t += R[i * KLD + l] * xr[q];
-                }
+            for (int i = 15; i >= 0; --i) {
+                double t = (i == c) ? 1.0 : 0.0;
 #pragma unroll
-                for (int off = 8; off > 0; off >>= 1) t += __shfl_xor(t, off);
-                const double xi = ((i == c) ? 1.0 - t : -t) * sg[i];
-                if ((i & 15) == r) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (q == (i >> 4)) xr[q] = xi;
-                }
+                for (int l = i + 1; l < 16; ++l) t -= R[(b0 + i) * KLD + b0 + l] * x[l];
+                x[i] = t * sg[b0 + i];
             }
-        }
-        if (c < k) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int l = r + 16 * q;
-                if (l < k) X[l * KLD + c] = (l <= c) ? xr[q] : 0.0;
-            }
+            for (int i = 0; i < 16; ++i) X[(b0 + i) * KLD + b0 + c] = x[i];   // (zero below the diagonal by construction)
         }
     }
     __syncthreads();
+    mm_kk(k, X, false, R, false, Q, 1.0);            // Q = D^-1 R
+    for (int e = tid; e < kp * 16; e += OW_THREADS) {   // N = Q - I: its diagonal blocks are D^-1 D - I = 0
+        const int i = e / 16, j = (i / 16) * 16 + e % 16;
+        Q[i * KLD + j] = 0.0;
+    }
+    __syncthreads();
+    mm_kk(k, Q, false, Q, false, R, 1.0);            // R = N^2
+    mm_kk(k, R, false, X, false, T, 1.0);            // T = N^2 D^-1
+    for (int e = tid; e < kp * kp; e += OW_THREADS) T[(e / kp) * KLD + e % kp] += X[(e / kp) * KLD + e % kp];   // W = (I + N^2) D^-1
+    __syncthreads();
+    mm_kk(k, Q, false, T, false, R, 1.0);            // R = N W
+    for (int e = tid; e < kp * kp; e += OW_THREADS) X[(e / kp) * KLD + e % kp] = T[(e / kp) * KLD + e % kp] - R[(e / kp) * KLD + e % kp];
+    __syncthreads();
 
     if (mode == 0) {
-        // Q = Yt[top] X
+        zero_image(T, k);
+        __syncthreads();
         for (int e = tid; e < k * k; e += OW_THREADS) {
-            const int a2 = e / k, b2 = e % k;
-            double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-            int l = 0;
-            for (; l + 3 <= b2; l += 4) {
-                t0 += T[a2 * KLD + l] * X[l * KLD + b2];
-                t1 += T[a2 * KLD + l + 1] * X[(l + 1) * KLD + b2];
-                t2 += T[a2 * KLD + l + 2] * X[(l + 2) * KLD + b2];
-                t3 += T[a2 * KLD + l + 3] * X[(l + 3) * KLD + b2];
-            }
-            for (; l <= b2; ++l) t0 += T[a2 * KLD + l] * X[l * KLD + b2];
-            Q[a2 * KLD + b2] = (t0 + t1) + (t2 + t3);
+            const int i = e / k, j = e % k;
+            const int64_t row = top_idx ? top_idx[i] : i;
+            T[i * KLD + j] = row < m ? static_cast<double>(Yt[row * ld + j]) : 0.0;  // top rows of Yt
         }
         __syncthreads();
+        mm_kk(k, T, false, X, false, Q, 1.0);   // Q = Yt[top] X
         // Householder signs from the modified LU of Q, one barrier per column: only the sign sequence is
         // wanted, so the multipliers are applied on the fly and never stored
         for (int i = 0; i < k; ++i) {
@@ -350,51 +393,18 @@ __global__ __launch_bounds__(OW_THREADS) void orth_weights_kernel(int64_t m, int
         const int i = e / k, j = e % k;
         const double x = X[i * KLD + j];
         Wo[e] = static_cast<float>(sq * sg[i] * x * sg[j]);
-        Rc_out[e] = R[i * KLD + j];
         Rinv_out[e] = x;
     }
     if (tid < k) signs_out[tid] = sg[tid];
     if (tid == 0) *info = bad;
 }
 
-// C = scale * op(A) op(B) for k x k matrices in LDS (row-major, leading dimension KLD); C may not
-// alias A or B.  Each thread owns a 4 x 4 block of C.
-__device__ void mm_kk(int k, const double* A, bool ta, const double* B, bool tb, double* C, double scale) {
-    const int nb = (k + 3) / 4;
-    for (int blk = threadIdx.x; blk < nb * nb; blk += 256) {
-        const int i0 = (blk / nb) * 4, j0 = (blk % nb) * 4;
-        double acc[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
-#pragma unroll 4
-        for (int l = 0; l < k; ++l) {
-            double av[4], bv[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int ii = min(i0 + i, k - 1), jj = min(j0 + i, k - 1);
-                av[i] = ta ? A[l * KLD + ii] : A[ii * KLD + l];
-                bv[i] = tb ? B[jj * KLD + l] : B[l * KLD + jj];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] += av[i] * bv[j];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (i0 + i < k && j0 + j < k) C[(i0 + i) * KLD + j0 + j] = scale * acc[i][j];
-    }
-    __syncthreads();
-}
-
 // Backward of Wo = sqrt(m) S Rc^-1 S through Rc = chol(G)^T:  H = Gbar + Gbar^T, so that
 // d loss / d Yt = Yt H for G = Yt^T Yt.
+// sixteen waves: the nine to sixteen result tiles of a product are in flight at once (four waves: 27.5 us at k = 47)
+constexpr int OWB_THREADS = 1024;
 template <typename TH>
-__global__ __launch_bounds__(256) void orth_weights_bwd_kernel(int64_t m, int k, const double* __restrict__ gWo,
+__global__ __launch_bounds__(OWB_THREADS) void orth_weights_bwd_kernel(int64_t m, int k, const double* __restrict__ gWo,
                                                                const double* __restrict__ Rc, const double* __restrict__ Rinv,
                                                                const double* __restrict__ signs, int mode,
                                                                TH* __restrict__ H) {
@@ -404,7 +414,12 @@ __global__ __launch_bounds__(256) void orth_weights_bwd_kernel(int64_t m, int k,
     __shared__ double L[SPARC_MAX_K * KLD];   // Rc (upper); L = Rc^T
     const int tid = threadIdx.x;
     const double sq = sqrt(static_cast<double>(m));
-    for (int e = tid; e < k * k; e += 256) {
+    zero_image(M, k);
+    zero_image(A, k);
+    zero_image(B, k);
+    zero_image(L, k);
+    __syncthreads();
+    for (int e = tid; e < k * k; e += OWB_THREADS) {
         const int i = e / k, j = e % k;
         M[i * KLD + j] = Rinv[e];
         L[i * KLD + j] = Rc[e];
@@ -415,13 +430,13 @@ __global__ __launch_bounds__(256) void orth_weights_bwd_kernel(int64_t m, int k,
     mm_kk(k, A, false, M, true, B, 1.0);    // B = Mbar M^T
     mm_kk(k, M, true, B, false, A, -1.0);   // A = Rbar = -M^T Mbar M^T
     // Lbar = tril(Rbar^T): B[i][j] = Rbar[j][i] for i >= j
-    for (int e = tid; e < k * k; e += 256) {
+    for (int e = tid; e < k * k; e += OWB_THREADS) {
         const int i = e / k, j = e % k;
         B[i * KLD + j] = (i >= j) ? A[j * KLD + i] : 0.0;
     }
     __syncthreads();
     mm_kk(k, L, false, B, false, A, 1.0);   // A = L^T Lbar = Rc Lbar
-    for (int e = tid; e < k * k; e += 256) {
+    for (int e = tid; e < k * k; e += OWB_THREADS) {
         const int i = e / k, j = e % k;
         const double v = A[i * KLD + j];
         A[i * KLD + j] = (i > j) ? v : (i == j ? 0.5 * v : 0.0);  // Phi
@@ -429,7 +444,7 @@ __global__ __launch_bounds__(256) void orth_weights_bwd_kernel(int64_t m, int k,
     __syncthreads();
     mm_kk(k, M, false, A, false, B, 1.0);   // B = M Phi
     mm_kk(k, B, false, M, true, A, 1.0);    // A = Gbar = M Phi M^T
-    for (int e = tid; e < k * k; e += 256) {
+    for (int e = tid; e < k * k; e += OWB_THREADS) {
         const int i = e / k, j = e % k;
         H[e] = static_cast<TH>(A[i * KLD + j] + A[j * KLD + i]);
     }
@@ -639,7 +654,7 @@ extern "C" int sparc_orth_weights(int64_t m, int k, const double* G, const float
 extern "C" int sparc_orth_weights_bwd(int64_t m, int k, const double* gWo, const double* Rc, const double* Rinv,
                                       const double* signs, int mode, float* H, sparc_stream_t stream) {
     if (m <= 0 || k < 1 || k > SPARC_MAX_K || !gWo || !Rc || !Rinv || !signs || !H) return SPARC_ERR_ARG;
-    hipLaunchKernelGGL(orth_weights_bwd_kernel<float>, dim3(1), dim3(256), 0, stream, m, k, gWo, Rc, Rinv, signs, mode, H);
+    hipLaunchKernelGGL(orth_weights_bwd_kernel<float>, dim3(1), dim3(OWB_THREADS), 0, stream, m, k, gWo, Rc, Rinv, signs, mode, H);
     SPARC_CHECK_LAUNCH();
     return SPARC_OK;
 }
@@ -647,7 +662,7 @@ extern "C" int sparc_orth_weights_bwd(int64_t m, int k, const double* gWo, const
 extern "C" int sparc_orth_weights_bwd_f64(int64_t m, int k, const double* gWo, const double* Rc, const double* Rinv,
                                           const double* signs, int mode, double* H, sparc_stream_t stream) {
     if (m <= 0 || k < 1 || k > SPARC_MAX_K || !gWo || !Rc || !Rinv || !signs || !H) return SPARC_ERR_ARG;
-    hipLaunchKernelGGL(orth_weights_bwd_kernel<double>, dim3(1), dim3(256), 0, stream, m, k, gWo, Rc, Rinv, signs, mode, H);
+    hipLaunchKernelGGL(orth_weights_bwd_kernel<double>, dim3(1), dim3(OWB_THREADS), 0, stream, m, k, gWo, Rc, Rinv, signs, mode, H);
     SPARC_CHECK_LAUNCH();
     return SPARC_OK;
 }

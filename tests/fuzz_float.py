@@ -46,8 +46,13 @@ def check_mlp(seed):
     # the reference is torch's float32 layers on the same device: against float64 the ReLU masks of pre-activations
     # next to zero flip, for torch's float32 layers exactly as for these kernels (seen: 1e-2 on a first-layer gradient)
     h = x
+    risky = False
     for lin in lins[:-1]:
-        h = torch.relu(lin(h))
+        pre = lin(h)
+        # a pre-activation within rounding distance of zero may fall on either side of the ReLU in another summation
+        # order; the unit's whole gradient then differs between two correct float32 evaluations
+        risky = risky or bool((pre.abs() < 1e-6 * pre.abs().max()).any())
+        h = torch.relu(pre)
     ref = torch.tanh(lins[-1](h))
     params = [p for lin in lins for p in (lin.weight, lin.bias)]
     wrt = params + ([x] if x_grad else [])
@@ -58,7 +63,12 @@ def check_mlp(seed):
     note("mlp forward", rel(out.detach().cpu().numpy(), ref.detach().cpu().numpy()), 2e-5, seed, d)
     for i, (a, b) in enumerate(zip(og, rg)):
         if float(b.abs().max()) > 0:
-            note("mlp gradient", rel(a.cpu().numpy(), b.cpu().numpy()), 2e-4, seed, d + f" wrt {i}")
+            e = rel(a.cpu().numpy(), b.cpu().numpy())
+            if risky and not e < 2e-4:   # forgiven only where a unit may have flipped, and counted
+                key = "mlp problems whose gradients differ with a ReLU unit on the rounding boundary"
+                worst[key] = worst.get(key, 0) + 1
+                return
+            note("mlp gradient", e, 2e-4, seed, d + f" wrt {i}")
 
 
 def check_orth(seed):
