@@ -307,6 +307,14 @@ int sparc_wgrad_small(int64_t m, int n_out, int n_in, const float* g, int64_t ld
 size_t sparc_first_layer_bwd_workspace_bytes(int din, int n);
 int sparc_first_layer_bwd(int64_t m, int din, int n, const float* x, int64_t ldx, const float* g, int64_t ldg,
                           const float* h, int64_t ldh, float* dWt_db, void* ws, size_t ws_bytes, sparc_stream_t stream);
+/* The same without reading the layer's activations h: for a layer of at most 16 inputs whose forward was
+ * sparc_linear_narrow_in_fwd, the sign of every pre-activation is recomputed from x, W [n][din] and b [n] with that
+ * kernel's own sequence of fused multiply-adds (bit for bit the forward's value), which halves the traffic of the
+ * pass.  Same part of the reference's backward as sparc_first_layer_bwd (autograd of src/SpectralTrainer.py:28-39
+ * through loss.backward(), :237). */
+int sparc_first_layer_bwd_recompute(int64_t m, int din, int n, const float* x, int64_t ldx, const float* g,
+                                    int64_t ldg, const float* W, const float* b, float* dWt_db, void* ws,
+                                    size_t ws_bytes, sparc_stream_t stream);
 int sparc_linear_narrow_fwd(int64_t m, int K, int n_out, int act, const float* x, int64_t ldx, const float* W,
                             const float* b, float* out, int64_t ldo, sparc_stream_t stream);
 size_t sparc_dgrad_narrow_relu_workspace_bytes(int64_t m, int N);

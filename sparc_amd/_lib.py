@@ -71,6 +71,7 @@ _SIGS = {
     "sparc_wgrad_small": (c_int, [c_int64, c_int, c_int, P, c_int64, P, c_int64, P, P, c_size_t, P]),
     "sparc_first_layer_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
     "sparc_first_layer_bwd": (c_int, [c_int64, c_int, c_int, P, c_int64, P, c_int64, P, c_int64, P, P, c_size_t, P]),
+    "sparc_first_layer_bwd_recompute": (c_int, [c_int64, c_int, c_int, P, c_int64, P, c_int64, P, P, P, P, c_size_t, P]),
     "sparc_linear_narrow_fwd": (c_int, [c_int64, c_int, c_int, c_int, P, c_int64, P, P, P, c_int64, P]),
     "sparc_linear_narrow_in_fwd": (c_int, [c_int64, c_int, c_int, c_int, P, c_int64, P, P, P, c_int64, P]),
     "sparc_dgrad_narrow_relu_workspace_bytes": (c_size_t, [c_int64, c_int]),

@@ -141,10 +141,30 @@ ActPlan act_plan(int64_t m, int n, bool aligned) {
 // formed on the fly as h * [hmask > 0] (incoming gradient times the ReLU derivative, never written
 // out) and the narrow operand gets one more column of ones, so that row n_out of the result is the
 // column sum of the masked operand: the bias gradient.
-template <int NT, bool FIRST>
+// FIRST == 2: the layer's activations are not read at all (half of the pass's traffic): when the forward
+// was linear_narrow_in_fwd_kernel, a pre-activation is b + sum_k x[k] W[c][k] accumulated by fused
+// multiply-adds in the order k = 0, 1, ..., so the same sequence here gives the same bits and the same sign.
+// A lane owns four columns (their weights stay in registers); the row's x[k] sits in lane k of the lane's
+// 16-lane group (the narrow operand's own loads) and is broadcast from there (hmask = W [n_in][n_out], wb = b).
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+template <int K0, int KMAX>
+__device__ __forceinline__ void preact_steps(v2f_t (&a)[2], const float xr, const v2f_t (&w)[2][KMAX], const int K) {
+    if constexpr (K0 < KMAX) {
+        if (K0 < K) {   // uniform
+            const float xk = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(xr), 0x150 + K0, 0xf, 0xf, false));
+            a[0] = __builtin_elementwise_fma(v2f_t{xk, xk}, w[0][K0], a[0]);   // packed: two columns per instruction
+            a[1] = __builtin_elementwise_fma(v2f_t{xk, xk}, w[1][K0], a[1]);
+            preact_steps<K0 + 1, KMAX>(a, xr, w, K);
+        }
+    }
+}
+
+// KMAX (FIRST == 2): the layer's input columns rounded up to a multiple of four (registers for 4 x KMAX weights)
+template <int NT, int FIRST, int KMAX = 4>
 __global__ __launch_bounds__(256) void wgrad_small_kernel(int64_t m, int n_out, int n_in, const float* __restrict__ g,
                                                           int64_t ldg, const float* __restrict__ h, int64_t ldh,
                                                           const float* __restrict__ hmask, int64_t ldm,
+                                                          const float* __restrict__ wb,
                                                           float* __restrict__ partial, int64_t rows_per_block) {
     extern __shared__ float sm[];  // [4 waves][NT * 16][64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -163,7 +183,22 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(int64_t m, int n_out, 
         for (int t = 0; t < 4; ++t) acc[a][t] = v4f{0.f, 0.f, 0.f, 0.f};
 
     const float* hp = h + (int64_t)blk * 64 + 4 * jj;
-    const float* mp = FIRST ? hmask + (int64_t)blk * 64 + 4 * jj : nullptr;
+    const float* mp = FIRST == 1 ? hmask + (int64_t)blk * 64 + 4 * jj : nullptr;
+    v2f_t lw[2][KMAX], lb[2];   // FIRST == 2: the layer's weights and bias of this lane's four columns, in pairs
+    if (FIRST == 2) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int64_t c = (int64_t)blk * 64 + 4 * jj + 2 * t;
+            lb[t] = v2f_t{wb[c], wb[c + 1]};
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) lw[t][k] = k < n_out ? v2f_t{hmask[c * n_out + k], hmask[(c + 1) * n_out + k]} : v2f_t{0.f, 0.f};
+        }
+    }
+    auto recomputed = [&](const float xr) {   // the pre-activations of this lane's columns in the row whose x is xr
+        v2f_t a[2] = {lb[0], lb[1]};
+        preact_steps<0, KMAX>(a, xr, lw, n_out);
+        return make_float4(a[0][0], a[0][1], a[1][0], a[1][1]);
+    };
     int gcol[NT];
     bool gok[NT], gone[NT];
 #pragma unroll
@@ -197,12 +232,13 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(int64_t m, int n_out, 
         for (int u = 0; u < 4; ++u) {
             const int64_t r = rb + 4 * u + kk;
             hb[u] = *reinterpret_cast<const float4*>(hp + r * ldh);
-            if (FIRST) hm[u] = *reinterpret_cast<const float4*>(mp + r * ldm);
+            if (FIRST == 1) hm[u] = *reinterpret_cast<const float4*>(mp + r * ldm);
 #pragma unroll
             for (int a = 0; a < NT; ++a) ga[u][a] = g[r * ldg + gcol[a]];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
+            if (FIRST == 2) hm[u] = recomputed(ga[u][0]);   // (from the loaded values: lane k < n_out holds x[k])
 #pragma unroll
             for (int a = 0; a < NT; ++a) ga[u][a] = gok[a] ? ga[u][a] : (gone[a] ? 1.f : 0.f);
             if (FIRST) hb[u] = masked(hb[u], hm[u]);
@@ -214,10 +250,11 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(int64_t m, int n_out, 
         const bool live = r < w1;
         const int64_t rc = live ? r : w1 - 1;
         float4 hb = *reinterpret_cast<const float4*>(hp + rc * ldh);
-        if (FIRST) hb = masked(hb, *reinterpret_cast<const float4*>(mp + rc * ldm));
+        if (FIRST == 1) hb = masked(hb, *reinterpret_cast<const float4*>(mp + rc * ldm));
         float ga[NT];
 #pragma unroll
         for (int a = 0; a < NT; ++a) ga[a] = g[rc * ldg + gcol[a]];
+        if (FIRST == 2) hb = masked(hb, recomputed(ga[0]));
         if (!live) hb = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int a = 0; a < NT; ++a) ga[a] = !live ? 0.f : (gok[a] ? ga[a] : (gone[a] ? 1.f : 0.f));
@@ -543,8 +580,8 @@ extern "C" size_t sparc_wgrad_small_workspace_bytes(int n_out, int n_in) {
 }
 
 namespace {
-int wgrad_launch(bool first, int64_t m, int n_out, int n_rows_out, int n_in, const float* g, int64_t ldg, const float* h,
-                 int64_t ldh, const float* hmask, int64_t ldm, float* dW, void* ws, sparc_stream_t stream) {
+int wgrad_launch(int first, int64_t m, int n_out, int n_rows_out, int n_in, const float* g, int64_t ldg, const float* h,
+                 int64_t ldh, const float* hmask, int64_t ldm, const float* wb, float* dW, void* ws, sparc_stream_t stream) {
     const int nt = (n_rows_out + 15) / 16;
     int64_t rpb = (m + WGRAD_CHUNKS - 1) / WGRAD_CHUNKS;
     if (rpb < WGRAD_CHUNK_ROWS) rpb = WGRAD_CHUNK_ROWS;
@@ -555,20 +592,30 @@ int wgrad_launch(bool first, int64_t m, int n_out, int n_rows_out, int n_in, con
     const size_t lds = (size_t)4 * nt * 16 * 64 * sizeof(float);
 #define SPARC_WGRAD(NT_, F_)                                                                                              \
     hipLaunchKernelGGL((wgrad_small_kernel<NT_, F_>), grid, dim3(256), lds, stream, m, n_out, n_in, g, ldg, h, ldh, hmask, \
-                       ldm, partial, rpb)
-    if (first) {
+                       ldm, wb, partial, rpb)
+    if (first == 2) {   // at most 16 input columns: one tile with the column of ones, two for 16 columns
+#define SPARC_WGRAD2(NT_, KM_)                                                                                             \
+    hipLaunchKernelGGL((wgrad_small_kernel<NT_, 2, KM_>), grid, dim3(256), lds, stream, m, n_out, n_in, g, ldg, h, ldh, hmask, \
+                       ldm, wb, partial, rpb)
+        if (n_out <= 4) SPARC_WGRAD2(1, 4);
+        else if (n_out <= 8) SPARC_WGRAD2(1, 8);
+        else if (n_out <= 12) SPARC_WGRAD2(1, 12);
+        else if (nt == 1) SPARC_WGRAD2(1, 16);
+        else SPARC_WGRAD2(2, 16);
+#undef SPARC_WGRAD2
+    } else if (first) {
         switch (nt) {
-            case 1: SPARC_WGRAD(1, true); break;
-            case 2: SPARC_WGRAD(2, true); break;
-            case 3: SPARC_WGRAD(3, true); break;
-            default: SPARC_WGRAD(4, true); break;
+            case 1: SPARC_WGRAD(1, 1); break;
+            case 2: SPARC_WGRAD(2, 1); break;
+            case 3: SPARC_WGRAD(3, 1); break;
+            default: SPARC_WGRAD(4, 1); break;
         }
     } else {
         switch (nt) {
-            case 1: SPARC_WGRAD(1, false); break;
-            case 2: SPARC_WGRAD(2, false); break;
-            case 3: SPARC_WGRAD(3, false); break;
-            default: SPARC_WGRAD(4, false); break;
+            case 1: SPARC_WGRAD(1, 0); break;
+            case 2: SPARC_WGRAD(2, 0); break;
+            case 3: SPARC_WGRAD(3, 0); break;
+            default: SPARC_WGRAD(4, 0); break;
         }
     }
 #undef SPARC_WGRAD
@@ -588,7 +635,7 @@ extern "C" int sparc_wgrad_small(int64_t m, int n_out, int n_in, const float* g,
         return SPARC_ERR_ARG;
     if (ws_bytes < sparc_wgrad_small_workspace_bytes(n_out, n_in) || !ws || (reinterpret_cast<uintptr_t>(ws) & 255)) return SPARC_ERR_WS;
     if (m == 0) return hipMemsetAsync(dW, 0, (size_t)n_out * n_in * sizeof(float), stream) == hipSuccess ? SPARC_OK : SPARC_ERR_LAUNCH;
-    return wgrad_launch(false, m, n_out, n_out, n_in, g, ldg, h, ldh, nullptr, 0, dW, ws, stream);
+    return wgrad_launch(0, m, n_out, n_out, n_in, g, ldg, h, ldh, nullptr, 0, nullptr, dW, ws, stream);
 }
 
 extern "C" size_t sparc_first_layer_bwd_workspace_bytes(int din, int n) {
@@ -604,7 +651,19 @@ extern "C" int sparc_first_layer_bwd(int64_t m, int din, int n, const float* x, 
     if (ws_bytes < sparc_first_layer_bwd_workspace_bytes(din, n) || !ws || (reinterpret_cast<uintptr_t>(ws) & 255)) return SPARC_ERR_WS;
     if (m == 0)
         return hipMemsetAsync(dWt_db, 0, (size_t)(din + 1) * n * sizeof(float), stream) == hipSuccess ? SPARC_OK : SPARC_ERR_LAUNCH;
-    return wgrad_launch(true, m, din, din + 1, n, x, ldx, g, ldg, h, ldh, dWt_db, ws, stream);
+    return wgrad_launch(1, m, din, din + 1, n, x, ldx, g, ldg, h, ldh, nullptr, dWt_db, ws, stream);
+}
+
+extern "C" int sparc_first_layer_bwd_recompute(int64_t m, int din, int n, const float* x, int64_t ldx, const float* g, int64_t ldg,
+                                               const float* W, const float* b, float* dWt_db, void* ws, size_t ws_bytes,
+                                               sparc_stream_t stream) {
+    if (m < 0 || din <= 0 || din > 16 || n <= 0 || n % 64 != 0 || !x || !g || !W || !b || !dWt_db || ldx < din || ldg < n ||
+        ldg % 4 != 0 || !aligned16(g))
+        return SPARC_ERR_ARG;
+    if (ws_bytes < sparc_first_layer_bwd_workspace_bytes(din, n) || !ws || (reinterpret_cast<uintptr_t>(ws) & 255)) return SPARC_ERR_WS;
+    if (m == 0)
+        return hipMemsetAsync(dWt_db, 0, (size_t)(din + 1) * n * sizeof(float), stream) == hipSuccess ? SPARC_OK : SPARC_ERR_LAUNCH;
+    return wgrad_launch(2, m, din, din + 1, n, x, ldx, g, ldg, W, 0, b, dWt_db, ws, stream);
 }
 
 namespace {

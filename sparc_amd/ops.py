@@ -74,17 +74,24 @@ def wgrad_small(g: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
     return dW
 
 
-def first_layer_bwd(x: torch.Tensor, g: torch.Tensor, h: torch.Tensor):
+def first_layer_bwd(x: torch.Tensor, g: torch.Tensor, h: torch.Tensor, W: torch.Tensor | None = None,
+                    b: torch.Tensor | None = None):
     """(dW [n, din] as a transposed view, db [n]) of a Linear+ReLU layer whose input needs no gradient,
-    in one pass over g and h: the masked gradient is never written out."""
+    in one pass over g and h: the masked gradient is never written out.  With W and b (the layer's own
+    parameters, for a layer whose forward ran on linear_narrow_in_fwd: at most 16 inputs) the activations h
+    are not read either: the kernel recomputes the pre-activations' signs with the forward's arithmetic."""
     m, din = x.shape
-    n = h.shape[1]
-    out = torch.empty(din + 1, n, dtype=torch.float32, device=h.device)
+    n = g.shape[1]
+    out = torch.empty(din + 1, n, dtype=torch.float32, device=g.device)
     nbytes = lib.sparc_first_layer_bwd_workspace_bytes(din, n)
-    ws = Workspace.get(nbytes, h.device)
-    with torch.cuda.device(h.device):
-        check(lib.sparc_first_layer_bwd(m, din, n, _ptr(x), x.stride(0), _ptr(g), g.stride(0), _ptr(h), h.stride(0), _ptr(out),
-                                        _ptr(ws), nbytes, _stream()), "sparc_first_layer_bwd")
+    ws = Workspace.get(nbytes, g.device)
+    with torch.cuda.device(g.device):
+        if W is not None:
+            check(lib.sparc_first_layer_bwd_recompute(m, din, n, _ptr(x), x.stride(0), _ptr(g), g.stride(0), _ptr(W), _ptr(b),
+                                                      _ptr(out), _ptr(ws), nbytes, _stream()), "sparc_first_layer_bwd_recompute")
+        else:
+            check(lib.sparc_first_layer_bwd(m, din, n, _ptr(x), x.stride(0), _ptr(g), g.stride(0), _ptr(h), h.stride(0), _ptr(out),
+                                            _ptr(ws), nbytes, _stream()), "sparc_first_layer_bwd")
     return out[:din].t(), out[din]
 
 
@@ -155,13 +162,16 @@ class SpectralMLP(torch.autograd.Function):
         ctx.hook = hook
         Ws, bs = params[0::2], params[1::2]
         acts = [x]
+        ctx.first_own = False   # the first layer ran on linear_narrow_in_fwd: its backward can recompute the ReLU mask
         for W, b in zip(Ws[:-1], bs[:-1]):
             h = linear_narrow_in_fwd(acts[-1], W, b, ACT_RELU) if len(acts) == 1 else None
+            if len(acts) == 1 and h is not None:
+                ctx.first_own = True
             acts.append(h if h is not None else torch._addmm_activation(b, acts[-1], W.t()))
         y = linear_narrow_fwd(acts[-1], Ws[-1], bs[-1], ACT_TANH)
         if y is None:
             y = torch.addmm(bs[-1], acts[-1], Ws[-1].t()).tanh_()
-        ctx.save_for_backward(*acts, y, *Ws)
+        ctx.save_for_backward(*acts, y, *Ws, bs[0])
         ctx.n_layers = len(Ws)
         return y
 
@@ -170,7 +180,7 @@ class SpectralMLP(torch.autograd.Function):
         L = ctx.n_layers
         hook = ctx.hook
         saved = ctx.saved_tensors
-        acts, y, Ws = saved[:L], saved[L], saved[L + 1:]
+        acts, y, Ws, b_first = saved[:L], saved[L], saved[L + 1:2 * L + 1], saved[2 * L + 1]
         grads = [None] * (2 * L)
         need_x = ctx.needs_input_grad[0]
         # output layer: tanh derivative + bias gradient, weight gradient, input gradient (+ previous ReLU)
@@ -196,7 +206,8 @@ class SpectralMLP(torch.autograd.Function):
                 xin, hout = acts[l], acts[l + 1]
                 if (l == 0 and not need_x and xin.shape[1] < 64 and hout.shape[1] % 64 == 0 and xin.stride(1) == 1
                         and xin.dtype == torch.float32 and pending.data_ptr() % 16 == 0):
-                    dWt, db = first_layer_bwd(xin, pending, hout)
+                    own = ctx.first_own and Ws[0].is_contiguous() and xin.shape[1] <= 16
+                    dWt, db = first_layer_bwd(xin, pending, hout, Ws[0] if own else None, b_first if own else None)
                     grads[0], grads[1] = dWt, db
                     _layer_done(grads, 0, hook)
                     return (None, None, *grads)

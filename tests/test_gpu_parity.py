@@ -406,6 +406,27 @@ def test_first_layer_backward_matches_float64(dev, m, din, n):
     assert rel(db.cpu().numpy(), gp.sum(0).numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("m,din,n", [(3001, 10, 1024), (70, 16, 64), (5, 1, 128), (24491, 10, 256), (4099, 15, 192)])
+def test_first_layer_backward_with_recomputed_mask_is_bitwise_the_same(dev, m, din, n):
+    """The backward variant that does not read the layer's activations (it recomputes the sign of every pre-activation
+    with the forward kernel's own arithmetic) against the variant that reads them: the same bits, on inputs where many
+    pre-activations sit next to zero (small integers times powers of two, so that exact zeros and ties occur too)."""
+    from sparc_amd.ops import ACT_RELU, first_layer_bwd, linear_narrow_in_fwd
+    gen = torch.Generator(device=dev).manual_seed(m + din)
+    x = torch.randint(-3, 4, (m, din), device=dev, generator=gen).float() * 0.25
+    W = torch.randint(-3, 4, (n, din), device=dev, generator=gen).float() * 0.5 + 1e-3 * torch.randn(n, din, device=dev, generator=gen)
+    b = torch.randint(-2, 3, (n,), device=dev, generator=gen).float() * 0.125
+    W[: n // 4] = W[: n // 4].round()       # a quarter of the units with exactly representable sums: pre-activations of exactly zero
+    g = torch.randn(m, n, device=dev, generator=gen)
+    h = linear_narrow_in_fwd(x, W, b, ACT_RELU)
+    assert h is not None and float((h == 0).float().mean()) > 0.2
+    dW_read, db_read = first_layer_bwd(x, g, h)
+    dW_re, db_re = first_layer_bwd(x, g, None, W, b)
+    assert torch.equal(dW_read, dW_re) and torch.equal(db_read, db_re)
+    ref = (g.double() * (h > 0)).t() @ x.double()
+    assert rel(dW_re.cpu().numpy(), ref.cpu().numpy()) < 1e-5
+
+
 @pytest.mark.parametrize("m,K,n_out,act", [(3001, 512, 47, 1), (17, 16, 1, 0), (24491, 512, 64, 2), (100, 768, 33, 1)])
 def test_linear_narrow_fwd_matches_float64(dev, m, K, n_out, act):
     from sparc_amd.ops import linear_narrow_fwd
