@@ -381,6 +381,23 @@ int sparc_label_scores(int64_t n, const int64_t* rowptr, const int64_t* nbr, con
                        const int64_t* labels, int64_t n_labels, const uint8_t* label_ok, int exclude_own,
                        int64_t* best, int64_t* best_lab, int64_t* cur, sparc_stream_t stream);
 
+/* ---- optimiser step ----------------------------------------------------------------
+ * One update of torch.optim.Adam (defaults: amsgrad = False, maximize = False), as the reference steps it after
+ * every backward (src/SpectralTrainer.py:188, :238; src/AETrainer.py likewise), for all parameter tensors of a
+ * model in one launch.  tensors: a HOST array of n_tensors <= SPARC_ADAM_MAX_TENSORS records of device pointers
+ * (parameter, its gradient, first and second moment; float32, n elements each); step: the number of this update,
+ * counted from 1 (bias corrections 1 - beta^step).  The moments are updated in place. */
+#define SPARC_ADAM_MAX_TENSORS 32
+typedef struct {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    int64_t n;
+} sparc_adam_tensor_t;
+int sparc_adam_step(int n_tensors, const sparc_adam_tensor_t* tensors, double lr, double beta1, double beta2,
+                    double eps, double weight_decay, int64_t step, sparc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

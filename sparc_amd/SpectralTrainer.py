@@ -179,8 +179,11 @@ class SpectralTrainer:
             self._lr_tensor = torch.tensor(float(self.lr), device=self.device)
             self.optimizer = optim.Adam(self.spectral_net.parameters(), lr=self._lr_tensor, fused=True, capturable=True)
         else:
-            fused = torch.device(self.device).type == "cuda"
-            self.optimizer = optim.Adam(self.spectral_net.parameters(), lr=self.lr, fused=fused)  # one launch per step
+            if torch.device(self.device).type == "cuda":   # all parameter tensors in one launch that fills the chip
+                from .optim import Adam
+                self.optimizer = Adam(self.spectral_net.parameters(), lr=self.lr)
+            else:
+                self.optimizer = optim.Adam(self.spectral_net.parameters(), lr=self.lr)
         self.scheduler = optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, mode="min", factor=self.lr_decay,
                                                               patience=self.patience)
 

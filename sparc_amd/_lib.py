@@ -26,6 +26,11 @@ class Tiling(ctypes.Structure):
                 ("o_row", c_void_p), ("o_val", c_void_p), ("o_valT", c_void_p), ("row_scale", c_void_p)]
 
 
+class AdamTensor(ctypes.Structure):
+    """sparc_adam_tensor_t of include/sparc_hip.h."""
+    _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("n", c_int64)]
+
+
 class Blocks(ctypes.Structure):
     """sparc_blocks_t of include/sparc_hip.h: a host struct describing the dense diagonal blocks of a batch."""
     _fields_ = [("desc", c_void_p), ("ndesc", c_int32), ("max_p", c_int32), ("blk", c_void_p), ("blkT", c_void_p)]
@@ -76,6 +81,7 @@ _SIGS = {
     "sparc_linear_narrow_in_fwd": (c_int, [c_int64, c_int, c_int, c_int, P, c_int64, P, P, P, c_int64, P]),
     "sparc_dgrad_narrow_relu_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "sparc_dgrad_narrow_relu": (c_int, [c_int64, c_int, c_int, P, c_int64, P, P, c_int64, P, c_int64, P, P, c_size_t, P]),
+    "sparc_adam_step": (c_int, [c_int, P, c_double, c_double, c_double, c_double, c_double, c_int64, P]),
     "sparc_row_rank_values": (c_int, [c_int64, c_int64, P, c_int64, c_int, P, P, P]),
     "sparc_label_scores": (c_int, [c_int64, P, P, P, P, c_int64, P, c_int, P, P, P, P]),
     "sparc_subblock_workspace_bytes": (c_size_t, [c_int64, c_int64]),

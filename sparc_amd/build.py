@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsparc_hip.so")
-SOURCES = ["spmm.hip", "affinity_prep.hip", "orth.hip", "mlp.hip", "csr_build.hip", "subblock.hip", "select.hip", "blocks.hip", "partition.hip"]
+SOURCES = ["spmm.hip", "affinity_prep.hip", "orth.hip", "mlp.hip", "csr_build.hip", "subblock.hip", "select.hip", "blocks.hip", "partition.hip", "adam.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed"]
 
 

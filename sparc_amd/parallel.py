@@ -162,8 +162,11 @@ class ShardedSpectralTrainer:
         if self.hip_graph:
             self.lr = torch.tensor(float(lr), device=self.device)
             self.optimizer = torch.optim.Adam(self.net.parameters(), lr=self.lr, fused=True, capturable=True)
+        elif fused_adam and self.device.type == "cuda":
+            from .optim import Adam
+            self.optimizer = Adam(self.net.parameters(), lr=lr)
         else:
-            self.optimizer = torch.optim.Adam(self.net.parameters(), lr=lr, fused=fused_adam)
+            self.optimizer = torch.optim.Adam(self.net.parameters(), lr=lr)
         self._graphed = None
         self.criterion = criterion
         self.reducer = None

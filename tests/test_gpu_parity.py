@@ -1150,3 +1150,43 @@ def test_training_separates_planted_clusters(dev, tmp_path, monkeypatch, capsys)
     acc = float((pred == label[held]).mean())
     print("planted clusters: loss", first, "->", last, "held-out accuracy", acc)
     assert acc > 0.9, acc
+
+
+@pytest.mark.parametrize("weight_decay", [0.0, 0.01])
+def test_one_launch_adam_matches_torch_adam(dev, weight_decay):
+    """sparc_adam_step against torch.optim.Adam (the optimiser of src/SpectralTrainer.py:188) over several steps with
+    a learning-rate change between them, on tensors of ragged sizes (tails that are no multiple of four, a view at an
+    address that is no multiple of sixteen bytes, an empty tensor, one tensor without a gradient)."""
+    from sparc_amd.optim import Adam
+    torch.manual_seed(3)
+    shapes = [(1024, 500), (1024,), (513, 7), (47,), (1,), (0,), (32, 33)]
+    base = [torch.randn(s, device=dev) for s in shapes]
+    odd = torch.randn(1 + 301, device=dev)
+    mine = [torch.nn.Parameter(b.clone()) for b in base] + [torch.nn.Parameter(odd.clone()[1:])]
+    ref = [torch.nn.Parameter(b.clone()) for b in base] + [torch.nn.Parameter(odd.clone()[1:])]
+    assert mine[-1].data_ptr() % 16 != 0
+    skipped = torch.nn.Parameter(torch.randn(5, device=dev))
+    keep = skipped.detach().clone()
+    a = Adam(mine + [skipped], lr=1e-3, weight_decay=weight_decay)
+    b = torch.optim.Adam(ref, lr=1e-3, weight_decay=weight_decay)
+    for step in range(6):
+        if step == 3:
+            for o in (a, b):
+                o.param_groups[0]["lr"] = 1e-4
+        for p, q in zip(mine, ref):
+            g = torch.randn_like(p) * (10.0 ** (step - 3))
+            p.grad, q.grad = g.clone(), g.clone()
+        a.step()
+        b.step()
+        for i, (p, q) in enumerate(zip(mine, ref)):
+            if p.numel():
+                assert rel(p.detach().cpu().numpy(), q.detach().cpu().numpy()) < 1e-6, (step, i)
+    for p, q in zip(mine, ref):
+        if p.numel():
+            assert rel(a.state[p]["exp_avg"].cpu().numpy(), b.state[q]["exp_avg"].cpu().numpy()) < 1e-6
+            assert rel(a.state[p]["exp_avg_sq"].cpu().numpy(), b.state[q]["exp_avg_sq"].cpu().numpy()) < 1e-6
+    assert torch.equal(skipped.detach(), keep)
+    sd = a.state_dict()                                   # a torch Optimizer: its state round-trips
+    a2 = Adam(mine + [skipped], lr=1.0)
+    a2.load_state_dict(sd)
+    assert a2.param_groups[0]["lr"] == 1e-4 and a2.param_groups[0]["step"] == 6
