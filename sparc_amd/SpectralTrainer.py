@@ -22,7 +22,8 @@ import torch.nn as nn
 import torch.optim as optim
 
 from .graph import ClusterBatch, require_gpu
-from .ops import ACT_RELU, ACT_TANH, ORTH_CHOLESKY, ORTH_REFERENCE, LapLoss, LinearAct, OrthApply, OrthWeights, SpectralMLP, SplitRows
+from .ops import (ACT_RELU, ACT_TANH, ORTH_CHOLESKY, ORTH_REFERENCE, LapLoss, LinearAct, OrthApply, OrthPair, OrthWeights,
+                  SpectralMLP, SplitRows)
 
 
 class SpectralNetModel(nn.Module):
@@ -74,10 +75,14 @@ class SpectralNetModel(nn.Module):
         """The two forwards of one training step (src/SpectralTrainer.py:222-223 then :232) as ONE pass
         of the MLP over both batches: the parameters do not change between them, so the rows are the
         same; the orthonormalisation weights come from x_orth's rows and are applied to x_grad's."""
-        m2 = x_orth.shape[0]
-        Yt_orth, Yt_grad = SplitRows.apply(self.embed_pre_orth(torch.cat([x_orth, x_grad], dim=0)), m2)
-        self.orthonorm_weights = self._make_orthonorm_weights(Yt_orth, top_idx)
-        return OrthApply.apply(Yt_grad, self.orthonorm_weights)
+        m2, m1 = x_orth.shape[0], x_grad.shape[0]
+        Yt = self.embed_pre_orth(torch.cat([x_orth, x_grad], dim=0))
+        if m2 == 0 or m1 == 0:
+            Yt_orth, Yt_grad = SplitRows.apply(Yt, m2)
+            self.orthonorm_weights = self._make_orthonorm_weights(Yt_orth, top_idx)
+            return OrthApply.apply(Yt_grad, self.orthonorm_weights)
+        Y, self.orthonorm_weights = OrthPair.apply(Yt, m2, top_idx, self.orth_mode)   # one graph node for both parts
+        return Y
 
     def set_rotation_matrix(self, rotation_matrix):
         self.rotation_matrix = rotation_matrix

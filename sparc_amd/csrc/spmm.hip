@@ -745,6 +745,14 @@ __device__ __forceinline__ void outside_chunk(float (&acc0)[VEC], float (&acc1)[
 // (the epilogue writes it that way), the gather is a plain sum of operand rows (no weight streams, no
 // weight broadcasts), and the row factors come back in the epilogue (a.rowpat: {r, delta, delta / r, 1 / r} per row).
 // Padding entries of the in-window stream point at one extra, zeroed window row; outside entries keep a 0/1 weight.
+// Ablation switches for the per-slot memory operations (SPARC_DBG bits 8 / 16 / 32: no entry / own-row / row-factor
+// loads, 128: no store; timing experiments only, the results are wrong): compiled in only with -DSPARC_ABLATE
+// (tools/build_variant.sh), because the widest instantiations have no register to spare for them.
+#ifdef SPARC_ABLATE
+#define SPARC_ABLATED(bit) ((a.dbg & (bit)) != 0)
+#else
+#define SPARC_ABLATED(bit) false
+#endif
 template <int VEC, bool DUAL, int EPI, int WM>
 __global__ __launch_bounds__(WIN_MAX_THREADS) void spmm_win(const SpmmArgs a) {
     constexpr bool PAT = WM == 2;
@@ -835,14 +843,14 @@ __global__ __launch_bounds__(WIN_MAX_THREADS) void spmm_win(const SpmmArgs a) {
         int4 ri = make_int4(-1, 0, 0, 0);
         if (slot < nslots) ri = info[slot * 4 + g];
         s.ri = ri;
-        s.c0 = load_entries4<WT>(a, static_cast<unsigned>(ri.y) + lane4, lr < (ri.w & 0xffff) && !(a.dbg & 8));
+        s.c0 = load_entries4<WT>(a, static_cast<unsigned>(ri.y) + lane4, lr < (ri.w & 0xffff) && !SPARC_ABLATED(8));
         s.o0.addr = 0; s.o0.v = 0.f; s.o0.vt = 0.f;
         if (has_out) s.o0 = load_outside<WTO>(a, static_cast<unsigned>(ri.z) + lane1, lr < (ri.w >> 16));
 #pragma unroll
         for (int q = 0; q < VEC; ++q) s.x0[q] = 0.f;
-        if (EPI != EPI_STORE && !(a.dbg & 16)) load_vec<VEC>(s.x0, X0s + static_cast<int64_t>(ri.x >= 0 ? ri.x : 0) * RW);
+        if (EPI != EPI_STORE && !SPARC_ABLATED(16)) load_vec<VEC>(s.x0, X0s + static_cast<int64_t>(ri.x >= 0 ? ri.x : 0) * RW);
         s.rp = make_float4(1.f, 0.f, 0.f, 0.f);
-        if (PAT && !(a.dbg & 32)) s.rp = *reinterpret_cast<const float4*>(a.rowpat + static_cast<int64_t>(ri.x >= 0 ? ri.x : 0) * 4);
+        if (PAT && !SPARC_ABLATED(32)) s.rp = *reinterpret_cast<const float4*>(a.rowpat + static_cast<int64_t>(ri.x >= 0 ? ri.x : 0) * 4);
     };
 
     const int lane_base = lr * (VEC * 4) + (int)(unsigned long)(__attribute__((address_space(3))) const char*)tile;
@@ -904,7 +912,7 @@ __global__ __launch_bounds__(WIN_MAX_THREADS) void spmm_win(const SpmmArgs a) {
             for (int q = 0; q < VEC; ++q) acc[q] = right ? fmaf(cur.rp.z, own[q], acc[q]) : fmaf(cur.rp.x, acc[q], cur.rp.y * own[q]);
             if (right) oscale = cur.rp.x;   // the next pass gathers the A^T half pre-multiplied by r
         }
-        row_epilogue<VEC, DUAL, EPI>(a, row, lane, owner && !(a.dbg & 128), 8, cl, right, pre, lc, acc, outs ? outs + row * RW : nullptr, 0,
+        row_epilogue<VEC, DUAL, EPI>(a, row, lane, owner && !SPARC_ABLATED(128), 8, cl, right, pre, lc, acc, outs ? outs + row * RW : nullptr, 0,
                                      wloss, oscale);
     };
     if (AHEAD) {  // two slots in turn, so that no register that a load is still writing has to be copied

@@ -34,11 +34,12 @@ def gram(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     return G
 
 
-def orth_apply(Yt: torch.Tensor, Wo: torch.Tensor, transpose: bool = False) -> torch.Tensor:
+def orth_apply(Yt: torch.Tensor, Wo: torch.Tensor, transpose: bool = False, out: torch.Tensor = None) -> torch.Tensor:
+    """Yt Wo (or Yt Wo^T); out: float32 rows of stride out.stride(0) to write into (default: a new [m, k] tensor)."""
     m, k = Yt.shape
-    Z = torch.empty(m, k, dtype=torch.float32, device=Yt.device)
+    Z = torch.empty(m, k, dtype=torch.float32, device=Yt.device) if out is None else out
     with torch.cuda.device(Yt.device):
-        check(lib.sparc_orth_apply(m, k, _ptr(Yt), Yt.stride(0), _ptr(Wo), 1 if transpose else 0, _ptr(Z), k, _stream()),
+        check(lib.sparc_orth_apply(m, k, _ptr(Yt), Yt.stride(0), _ptr(Wo), 1 if transpose else 0, _ptr(Z), Z.stride(0), _stream()),
               "sparc_orth_apply")
     return Z
 
@@ -386,9 +387,8 @@ class OrthWeights(torch.autograd.Function):
         return code
 
     @staticmethod
-    def forward(ctx, Yt, top_idx, mode):
-        require_gpu(Yt.device)
-        Y = _f32c(Yt)
+    def weights(Y, top_idx, mode):
+        """(Wo float32 [k, k], saved float64 [2 k k + k] = Rc, Rinv, signs) for the contiguous-row batch Y [m, k]."""
         m, k = Y.shape
         if k > 64:
             raise ValueError("spectral dimension k must be <= 64")
@@ -406,30 +406,74 @@ class OrthWeights(torch.autograd.Function):
         with torch.cuda.device(dev):
             check(lib.sparc_orth_weights(m, k, _ptr(G), _ptr(Y), Y.stride(0), _ptr(tidx), int(mode), _ptr(Wo), _ptr(Rc),
                                          _ptr(Rinv), _ptr(signs), _ptr(info), _stream()), "sparc_orth_weights")
-        ctx.save_for_backward(Y, saved)
-        ctx.mode = int(mode)
         OrthWeights.last_info = info  # device int; non-zero = Gram matrix not positive definite (checked lazily)
         key = dev.index or 0
         if key not in OrthWeights.worst_info:
             OrthWeights.worst_info[key] = torch.zeros(1, dtype=torch.int32, device=dev)
         torch.maximum(OrthWeights.worst_info[key], info, out=OrthWeights.worst_info[key])   # no step goes unnoticed
+        return Wo, saved
+
+    @staticmethod
+    def weights_backward(Y, saved, gW64, mode, out):
+        """out [m, k] (float32 rows) = the gradient with respect to Y of a scalar whose gradient with respect to Wo is
+        gW64 (float64 [k, k]).  H stays in float64 and Y H is accumulated in float64: for an ill-conditioned batch the
+        entries of H cancel down to a product many orders of magnitude smaller."""
+        m, k = Y.shape
+        Rc, Rinv, signs = saved[:k * k], saved[k * k:2 * k * k], saved[2 * k * k:]
+        H = torch.empty(k, k, dtype=torch.float64, device=Y.device)
+        with torch.cuda.device(Y.device):
+            check(lib.sparc_orth_weights_bwd_f64(m, k, _ptr(gW64), _ptr(Rc), _ptr(Rinv), _ptr(signs), int(mode), _ptr(H),
+                                                 _stream()), "sparc_orth_weights_bwd_f64")
+            check(lib.sparc_orth_apply_f64(m, k, _ptr(Y), Y.stride(0), _ptr(H), _ptr(out), out.stride(0), _stream()),
+                  "sparc_orth_apply_f64")
+        return out
+
+    @staticmethod
+    def forward(ctx, Yt, top_idx, mode):
+        require_gpu(Yt.device)
+        Y = _f32c(Yt)
+        Wo, saved = OrthWeights.weights(Y, top_idx, mode)
+        ctx.save_for_backward(Y, saved)
+        ctx.mode = int(mode)
         return Wo
 
     @staticmethod
     def backward(ctx, gWo):
         Y, saved = ctx.saved_tensors
         m, k = Y.shape
-        Rc, Rinv, signs = saved[:k * k], saved[k * k:2 * k * k], saved[2 * k * k:]
-        g64 = gWo.detach().to(torch.float64).contiguous()
-        # H stays in float64 and Yt H is accumulated in float64: for an ill-conditioned batch the entries of H cancel
-        # down to a product many orders of magnitude smaller
-        H = torch.empty(k, k, dtype=torch.float64, device=Y.device)
         gY = torch.empty(m, k, dtype=torch.float32, device=Y.device)
-        with torch.cuda.device(Y.device):
-            check(lib.sparc_orth_weights_bwd_f64(m, k, _ptr(g64), _ptr(Rc), _ptr(Rinv), _ptr(signs), ctx.mode, _ptr(H),
-                                                 _stream()), "sparc_orth_weights_bwd_f64")
-            check(lib.sparc_orth_apply_f64(m, k, _ptr(Y), Y.stride(0), _ptr(H), _ptr(gY), k, _stream()), "sparc_orth_apply_f64")
+        OrthWeights.weights_backward(Y, saved, gWo.detach().to(torch.float64).contiguous(), ctx.mode, gY)
         return gY, None, None
+
+
+class OrthPair(torch.autograd.Function):
+    """The orthonormalisation of one training step as ONE node of the autograd graph: Yt [m2 + m1, k] holds the MLP's
+    output for the orthogonality batch (first m2 rows) and the gradient batch; the weights come from the first
+    (src/SpectralTrainer.py:222-223, :42-70) and are applied to the second (:232, :103).  Returns (Y [m1, k], Wo).
+    Same kernels as OrthWeights + OrthApply + SplitRows; as one node the backward writes both parts of the gradient
+    straight into one [m2 + m1, k] buffer (no concatenation) and the k x k gradient of the weights stays in float64
+    from the Gram product to the factorisation's backward (no casts)."""
+
+    @staticmethod
+    def forward(ctx, Yt, m2, top_idx, mode):
+        require_gpu(Yt.device)
+        Y = _f32c(Yt)
+        Wo, saved = OrthWeights.weights(Y[:m2], top_idx, mode)
+        out = orth_apply(Y[m2:], Wo)
+        ctx.save_for_backward(Y, Wo, saved)
+        ctx.m2, ctx.mode = int(m2), int(mode)
+        ctx.mark_non_differentiable(Wo)
+        return out, Wo
+
+    @staticmethod
+    def backward(ctx, gY, _gWo):
+        Y, Wo, saved = ctx.saved_tensors
+        m2 = ctx.m2
+        g = _f32c(gY)
+        gYt = torch.empty_like(Y)
+        orth_apply(g, Wo, transpose=True, out=gYt[m2:])
+        OrthWeights.weights_backward(Y[:m2], saved, gram(Y[m2:], g), ctx.mode, gYt[:m2])
+        return gYt, None, None, None
 
 
 class OrthApply(torch.autograd.Function):
