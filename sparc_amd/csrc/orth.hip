@@ -213,7 +213,124 @@ __device__ __forceinline__ void zero_image(double* M, int k) {
     for (int e = threadIdx.x; e < kp * kp; e += blockDim.x) M[(e / kp) * KLD + e % kp] = 0.0;
 }
 
-constexpr int OW_THREADS = 1024;
+constexpr int OW_THREADS = 512;
+#ifdef SPARC_OW_STAMPS
+__device__ long long g_ow_stamps[8];   // developer timeline of orth_weights_kernel (cycle counter at its phase boundaries)
+#endif
+
+// ---- blocked factorisations of a k x k LDS image, 16 columns at a time ------------------------------------------
+// A column-at-a-time factorisation costs a barrier and two LDS round trips per column (1200-1450 cycles each at
+// k = 47).  Here a 16 x 16 diagonal block is factored by ONE wave with a column of the block in the registers of
+// every lane (the pivot row reaches the other lanes through DPP broadcasts, no LDS, no barrier), the panels beside
+// it are solved by one thread per column (or row) with the block's factor read from LDS (the same address in all
+// lanes: broadcast reads), and the trailing matrix is updated on the f64 matrix cores: three barriers per 16 columns.
+
+template <int J>
+__device__ __forceinline__ double bcast16(const double x) {   // lane J of the 16-lane DPP row, in every lane of the row
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + J, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + J, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// trailing update of the block held in registers: d[i] -= l_i * u for i = I .. 15, l_i = lane I's `src` (Cholesky:
+// the scaled pivot row; LU: the multiplier column, passed per element)
+template <int J, int I>
+struct CholInner {
+    static __device__ __forceinline__ void run(double (&d)[16], const double fj) {
+        if constexpr (I < 16) {
+            d[I] -= bcast16<I>(fj) * fj;
+            CholInner<J, I + 1>::run(d, fj);
+        }
+    }
+};
+
+// Cholesky (upper) of the 16 x 16 block in registers: lane c holds column c, d[i] = element (i, c) of the current
+// Schur complement for i <= c (what it holds below the diagonal is never used).  On return d[i] = F[i][c] for i <= c;
+// lane J < 16 of the wave writes rd[J] = 1 / F[J][J] (write: only one of the four 16-lane copies does);
+// bad = 1 + the first column whose pivot is not positive, else 0.
+template <int J>
+__device__ __forceinline__ void chol_block(double (&d)[16], double* rd, const int c, const bool write, int& bad) {
+    if constexpr (J < 16) {
+        double piv = bcast16<J>(d[J]);
+        if (!(piv > 0.0)) {
+            if (!bad) bad = J + 1;
+            piv = 1e-300;
+        }
+        const double rs = fast_rsqrt(piv);
+        if (write && c == J) rd[J] = rs;
+        const double fj = d[J] * rs;
+        d[J] = fj;
+        CholInner<J, J + 1>::run(d, fj);
+#ifdef SPARC_OW_COLBAR
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        chol_block<J + 1>(d, rd, c, write, bad);
+    }
+}
+
+template <int J, int I>
+struct LuInner {
+    static __device__ __forceinline__ void run(double (&d)[16], const double ip, const bool right, const bool mine) {
+        if constexpr (I < 16) {
+            if (mine) d[I] *= ip;                       // the multiplier column: lane J scales its own entries
+            const double l = bcast16<J>(d[I]);          // L[I][J]
+            if (right) d[I] -= l * d[J];                // columns right of the pivot: element (I, c) -= L[I][J] U[J][c]
+            LuInner<J, I + 1>::run(d, ip, right, mine);
+        }
+    }
+};
+
+// The sign-tracking LU of the 16 x 16 block in registers: lane c holds column c, d[a] = element (a, c).  Step J:
+// sgn = -sign(q_JJ) (the reference's Householder sign), pivot q_JJ - sgn, multipliers below it, update to the right.
+// On return the block holds U on and above the diagonal and the multipliers below; lane J writes the sign of column
+// J to sgn_out[J] (if that column exists: J < ncols) and the reciprocal pivot to rd[J].
+template <int J>
+__device__ __forceinline__ void lu_block(double (&d)[16], double* sgn_out, double* rd, const int c, const bool write,
+                                         const int ncols) {
+    if constexpr (J < 16) {
+        const double qjj = bcast16<J>(d[J]);
+        const double sgn = qjj > 0.0 ? -1.0 : 1.0;
+        const double ip = fast_rcp(qjj - sgn);
+        if (write && c == J) {
+            if (J < ncols) sgn_out[J] = sgn;
+            rd[J] = ip;
+        }
+        LuInner<J, J + 1>::run(d, ip, c > J, c == J);
+#ifdef SPARC_OW_COLBAR
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        lu_block<J + 1>(d, sgn_out, rd, c, write, ncols);
+    }
+}
+
+// C[a][b] -= sum_l opA[a][l] opB[l][b] over the 16 inner indices of block jb, for the tiles of rows / columns
+// [jb + 16, 16 nt): opA[a][l] = ta ? A[jb + l][a] : A[a][jb + l], opB[l][b] = B[jb + l][b].  upper: only the tiles on
+// and above the diagonal.  One tile per wave in turn; ends with a barrier.
+__device__ __forceinline__ void trailing_update(const int jb, const int nt, const double* A, const bool ta, const double* B,
+                                                double* C, const bool upper) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int t0 = jb / 16 + 1, n = nt - t0;
+    for (int t = wave; t < n * n; t += nwaves) {
+        const int ti = t0 + t / n, tj = t0 + t % n;
+        if (upper && ti > tj) continue;
+        const int ar = 16 * ti + li, bc = 16 * tj + li;
+        double av[4], bv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int l = jb + 4 * i + lk;
+            av[i] = ta ? A[l * KLD + ar] : A[ar * KLD + l];
+            bv[i] = B[l * KLD + bc];
+        }
+        double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[i], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) C[(16 * ti + lk + 4 * q) * KLD + bc] -= acc[q];
+    }
+    __syncthreads();
+}
 
 // Single workgroup of 16 waves; the two factorisations are bound by LDS latency and the barrier of every column,
 // so their trailing updates give each thread at most 2 x 2 elements, fully unrolled; the inverse of the factor and
@@ -233,60 +350,62 @@ __global__ __launch_bounds__(OW_THREADS) void orth_weights_kernel(int64_t m, int
     __shared__ double Q[SPARC_MAX_K * KLD];
     __shared__ double T[SPARC_MAX_K * KLD];
     __shared__ double sg[SPARC_MAX_K];
+    __shared__ double rdiag[SPARC_MAX_K];   // reciprocal pivots of the block being factored
     __shared__ int bad;
     const int tid = threadIdx.x;
-    const int ty = tid >> 5, tx = tid & 31;  // 32 x 32 thread grid over the trailing matrix
+#ifdef SPARC_OW_STAMPS
+#define OW_STAMP(i) if (tid == 0) g_ow_stamps[i] = __builtin_readcyclecounter();
+#else
+#define OW_STAMP(i)
+#endif
+    OW_STAMP(0)
     if (tid == 0) bad = 0;
     zero_image(R, k);   // the products on the matrix cores read whole 16 x 16 tiles: zero beyond k
     zero_image(X, k);
+    zero_image(Q, k);   // (the factor's image: its trailing updates read whole tiles too)
     __syncthreads();
     for (int e = tid; e < k * k; e += OW_THREADS) R[(e / k) * KLD + e % k] = G[e];
+    if (tid >= k && tid < (k + 15) / 16 * 16) R[tid * KLD + tid] = 1.0;   // identity beyond k: the last block stays regular
     __syncthreads();
 
-    // Cholesky, upper: G = R^T R, ONE barrier per column.  The working matrix R keeps the unscaled Schur
-    // complement; the scaled pivot row goes to its own image (Q doubles as that image until it is needed
-    // for the top rows), so the trailing update of column j never races with the scaling of row j:
-    //     R[a][b] -= R[j][a] R[j][b] / R[j][j]        factor row:  F[j][c] = R[j][c] / sqrt(R[j][j])
+    OW_STAMP(1)
+    // Cholesky, upper: G = R^T R, in blocks of 16 columns (see above).  R keeps the Schur complement of the columns
+    // still to come; the factor's rows go to their own image (Q doubles as that image until it is needed for the
+    // top rows).
     double* F = Q;
-    for (int j = 0; j < k; ++j) {
-        double piv = R[j * KLD + j];
-        if (!(piv > 0.0)) {
-            if (tid == 0 && !bad) bad = j + 1;
-            piv = 1e-300;
-        }
-        const double rs = fast_rsqrt(piv);   // 1 / sqrt(piv)
-        const double ip = rs * rs;           // 1 / piv
-        if (tid < k - j) F[j * KLD + j + tid] = R[j * KLD + j + tid] * rs;
-        // trailing update: LDS instruction issue bounds a step, so waves whose rows lie outside the
-        // trailing matrix skip it, and the 2 x 2 form is only used while the matrix is wider than 32
-        const int a0 = j + 1 + ty, b0 = j + 1 + tx;
-        if (j + 1 + 2 * (tid >> 6) < k) {              // wave-uniform
-            if (k - (j + 1) > 32) {                    // uniform
-                double fa[2], rb[2], cur[2][2];
+    const int ntile = (k + 15) / 16;
+    for (int jb = 0; jb < k; jb += 16) {
+        if (tid < 64) {                                   // wave 0: the diagonal block, a column per lane (four copies)
+            const int c = tid & 15;
+            double d[16];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    fa[u] = (a0 + 32 * u < k) ? R[j * KLD + a0 + 32 * u] : 0.0;
-                    rb[u] = (b0 + 32 * u < k) ? R[j * KLD + b0 + 32 * u] : 0.0;
-                }
+            for (int i = 0; i < 16; ++i) d[i] = R[(jb + i) * KLD + jb + c];
+            int bd = 0;
+            chol_block<0>(d, rdiag + jb, c, tid < 16, bd);
+            if (tid < 16) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int v = 0; v < 2; ++v) {
-                        const int a2 = a0 + 32 * u, b2 = b0 + 32 * v;
-                        cur[u][v] = (b2 < k && a2 <= b2) ? R[a2 * KLD + b2] : 0.0;
-                    }
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int v = 0; v < 2; ++v) {
-                        const int a2 = a0 + 32 * u, b2 = b0 + 32 * v;
-                        if (b2 < k && a2 <= b2) R[a2 * KLD + b2] = cur[u][v] - fa[u] * ip * rb[v];
-                    }
-            } else if (b0 < k && a0 <= b0) {
-                R[a0 * KLD + b0] -= R[j * KLD + a0] * ip * R[j * KLD + b0];
+                for (int i = 0; i < 16; ++i) F[(jb + i) * KLD + jb + c] = (i <= c) ? d[i] : 0.0;
             }
+            if (tid == 0 && bd && !bad) bad = jb + bd;
         }
         __syncthreads();
+        if (jb + 16 >= k) break;
+        if (tid < k - (jb + 16)) {                        // the panel right of the block: forward substitution per column
+            const int c = jb + 16 + tid;
+            double v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = R[(jb + i) * KLD + c];
+#pragma unroll
+            for (int l = 0; l < 16; ++l) {                // (row l is final; the rows below it take their share at once:
+                v[l] *= rdiag[jb + l];                    // fifteen independent updates instead of one chain per row)
+#pragma unroll
+                for (int i = l + 1; i < 16; ++i) v[i] -= F[(jb + l) * KLD + jb + i] * v[l];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) F[(jb + i) * KLD + c] = v[i];
+        }
+        __syncthreads();
+        trailing_update(jb, ntile, F, true, F, R, true);   // R[a][b] -= sum_l F[jb + l][a] F[jb + l][b]
     }
     for (int e = tid; e < k * k; e += OW_THREADS) {
         const int i = e / k, j = e % k;
@@ -294,12 +413,11 @@ __global__ __launch_bounds__(OW_THREADS) void orth_weights_kernel(int64_t m, int
     }
     __syncthreads();
 
-    // X = R^-1.  With D the diagonal 16 x 16 blocks of R and N = D^-1 R - I (strictly block upper triangular, so
-    // N^4 = 0 for k <= 64):  R^-1 = (I + N)^-1 D^-1 = (I - N) (I + N^2) D^-1.
-    // D^-1: wave b inverts block b, lane c < 16 its column c by back substitution with the column in registers (the
-    // entries of R it needs are the same for all lanes: LDS broadcasts); the rest are four products on the matrix
-    // cores.  Rows beyond k are given a unit diagonal so that the blocks stay regular.  The factor itself is
-    // written out first: its image is reused.
+    OW_STAMP(2)
+    // X = R^-1 by blocks of 16: the diagonal blocks D_i^-1 first (wave b inverts block b, lane c < 16 its column c by
+    // back substitution with the column in registers; the entries of R it needs are the same for all lanes: LDS
+    // broadcasts), then the blocks above the diagonal on the matrix cores.  Rows beyond k are given a unit diagonal so
+    // that the blocks stay regular.
     const int kp = (k + 15) / 16 * 16;
     for (int e = tid; e < k * k; e += OW_THREADS) Rc_out[e] = R[(e / k) * KLD + e % k];
     if (tid >= k && tid < kp) R[tid * KLD + tid] = 1.0;
@@ -323,20 +441,41 @@ __global__ __launch_bounds__(OW_THREADS) void orth_weights_kernel(int64_t m, int
         }
     }
     __syncthreads();
-    mm_kk(k, X, false, R, false, Q, 1.0);            // Q = D^-1 R
-    for (int e = tid; e < kp * 16; e += OW_THREADS) {   // N = Q - I: its diagonal blocks are D^-1 D - I = 0
-        const int i = e / 16, j = (i / 16) * 16 + e % 16;
-        Q[i * KLD + j] = 0.0;
+    // the blocks above the diagonal, one block diagonal at a time: X_ij = -D_i^-1 (sum_{i < l <= j} R_il X_lj).  A wave
+    // owns a tile; the sum leaves the matrix cores in exactly the register layout their B operand wants (register q of
+    // a lane is row 4 q + (lane >> 4)), so the product with D_i^-1 follows without a trip through LDS.
+    {
+        const int lane = tid & 63, wave = tid >> 6, nwaves = OW_THREADS / 64;
+        const int li = lane & 15, lk = lane >> 4, nt = kp / 16;
+        for (int dl = 1; dl < nt; ++dl) {
+            for (int t = wave; t < nt - dl; t += nwaves) {
+                const int i = t, j = t + dl;
+                double4_t sum = double4_t{0.0, 0.0, 0.0, 0.0};
+                for (int l = i + 1; l <= j; ++l) {
+                    double av[4], bv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int kk = 16 * l + 4 * u + lk;
+                        av[u] = R[(16 * i + li) * KLD + kk];
+                        bv[u] = X[kk * KLD + 16 * j + li];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) sum = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], sum, 0, 0, 0);
+                }
+                double dv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) dv[u] = X[(16 * i + li) * KLD + 16 * i + 4 * u + lk];
+                double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(dv[u], sum[u], acc, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) X[(16 * i + lk + 4 * q) * KLD + 16 * j + li] = -acc[q];
+            }
+            __syncthreads();
+        }
     }
-    __syncthreads();
-    mm_kk(k, Q, false, Q, false, R, 1.0);            // R = N^2
-    mm_kk(k, R, false, X, false, T, 1.0);            // T = N^2 D^-1
-    for (int e = tid; e < kp * kp; e += OW_THREADS) T[(e / kp) * KLD + e % kp] += X[(e / kp) * KLD + e % kp];   // W = (I + N^2) D^-1
-    __syncthreads();
-    mm_kk(k, Q, false, T, false, R, 1.0);            // R = N W
-    for (int e = tid; e < kp * kp; e += OW_THREADS) X[(e / kp) * KLD + e % kp] = T[(e / kp) * KLD + e % kp] - R[(e / kp) * KLD + e % kp];
-    __syncthreads();
 
+    OW_STAMP(3)
     if (mode == 0) {
         zero_image(T, k);
         __syncthreads();
@@ -347,47 +486,59 @@ __global__ __launch_bounds__(OW_THREADS) void orth_weights_kernel(int64_t m, int
         }
         __syncthreads();
         mm_kk(k, T, false, X, false, Q, 1.0);   // Q = Yt[top] X
-        // Householder signs from the modified LU of Q, one barrier per column: only the sign sequence is
-        // wanted, so the multipliers are applied on the fly and never stored
-        for (int i = 0; i < k; ++i) {
-            const double qii = Q[i * KLD + i];
-            const double sgn = qii > 0.0 ? -1.0 : 1.0;
-            const double inv_piv = fast_rcp(qii - sgn);
-            if (tid == 0) sg[i] = sgn;
-            const int a0 = i + 1 + ty, b0 = i + 1 + tx;
-            if (i + 1 + 2 * (tid >> 6) < k) {              // wave-uniform
-                if (k - (i + 1) > 32) {                    // uniform
-                    double fa[2], rb[2], cur[2][2];
+        OW_STAMP(4)
+        // Householder signs from the modified LU of Q, in blocks of 16 columns: only the sign sequence is wanted.
+        // (Q is zero beyond k; a zero diagonal there gives a pivot of 1 and no multipliers.)
+        for (int jb = 0; jb < k; jb += 16) {
+            if (tid < 64) {                               // wave 0: the diagonal block, a column per lane
+                const int c = tid & 15;
+                double d[16];
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        fa[u] = (a0 + 32 * u < k) ? Q[(a0 + 32 * u) * KLD + i] : 0.0;
-                        rb[u] = (b0 + 32 * u < k) ? Q[i * KLD + b0 + 32 * u] : 0.0;
-                    }
+                for (int a = 0; a < 16; ++a) d[a] = Q[(jb + a) * KLD + jb + c];
+                lu_block<0>(d, sg + jb, rdiag + jb, c, tid < 16, k - jb);
+                if (tid < 16) {
 #pragma unroll
-                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                        for (int v = 0; v < 2; ++v) {
-                            const int a2 = a0 + 32 * u, b2 = b0 + 32 * v;
-                            cur[u][v] = (a2 < k && b2 < k) ? Q[a2 * KLD + b2] : 0.0;
-                        }
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                        for (int v = 0; v < 2; ++v) {
-                            const int a2 = a0 + 32 * u, b2 = b0 + 32 * v;
-                            if (a2 < k && b2 < k) Q[a2 * KLD + b2] = cur[u][v] - fa[u] * inv_piv * rb[v];
-                        }
-                } else if (a0 < k && b0 < k) {
-                    Q[a0 * KLD + b0] -= Q[a0 * KLD + i] * inv_piv * Q[i * KLD + b0];
+                    for (int a = 0; a < 16; ++a) Q[(jb + a) * KLD + jb + c] = d[a];
                 }
             }
             __syncthreads();
+            if (jb + 16 >= k) break;
+            const int nrest = k - (jb + 16);
+            if (tid < nrest) {                            // the rows of U right of the block: unit-lower solve per column
+                const int c = jb + 16 + tid;
+                double v[16];
+#pragma unroll
+                for (int a = 0; a < 16; ++a) v[a] = Q[(jb + a) * KLD + c];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+#pragma unroll
+                    for (int a = i + 1; a < 16; ++a) v[a] -= Q[(jb + a) * KLD + jb + i] * v[i];
+                }
+#pragma unroll
+                for (int a = 0; a < 16; ++a) Q[(jb + a) * KLD + c] = v[a];
+            } else if (tid >= 64 && tid - 64 < nrest) {   // the multipliers below the block: one row per thread
+                const int r = jb + 16 + tid - 64;
+                double w[16];
+#pragma unroll
+                for (int b = 0; b < 16; ++b) w[b] = Q[r * KLD + jb + b];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    w[i] *= rdiag[jb + i];
+#pragma unroll
+                    for (int b = i + 1; b < 16; ++b) w[b] -= w[i] * Q[(jb + i) * KLD + jb + b];
+                }
+#pragma unroll
+                for (int b = 0; b < 16; ++b) Q[r * KLD + jb + b] = w[b];
+            }
+            __syncthreads();
+            trailing_update(jb, ntile, Q, false, Q, Q, false);   // Q[a][b] -= sum_l L[a][jb + l] U[jb + l][b]
         }
     } else if (tid < k) {
         sg[tid] = 1.0;
     }
     __syncthreads();
 
+    OW_STAMP(5)
     const double sq = sqrt(static_cast<double>(m));
     for (int e = tid; e < k * k; e += OW_THREADS) {
         const int i = e / k, j = e % k;
@@ -397,6 +548,7 @@ __global__ __launch_bounds__(OW_THREADS) void orth_weights_kernel(int64_t m, int
     }
     if (tid < k) signs_out[tid] = sg[tid];
     if (tid == 0) *info = bad;
+    OW_STAMP(6)
 }
 
 // Backward of Wo = sqrt(m) S Rc^-1 S through Rc = chol(G)^T:  H = Gbar + Gbar^T, so that
@@ -686,3 +838,9 @@ extern "C" int sparc_orth_apply(int64_t m, int k, const float* Yt, int64_t ld, c
     SPARC_CHECK_LAUNCH();
     return SPARC_OK;
 }
+
+#ifdef SPARC_OW_STAMPS
+extern "C" int sparc_debug_orth_stamps(long long* host_out) {   // developer builds only
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ow_stamps), 8 * sizeof(long long)) == hipSuccess ? SPARC_OK : SPARC_ERR_LAUNCH;
+}
+#endif
