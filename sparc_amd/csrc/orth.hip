@@ -153,6 +153,9 @@ __global__ __launch_bounds__(256) void gram_reduce(int kk, int nparts, const dou
 
 // 1 / sqrt(x) in float64: the hardware estimate refined by two Newton steps
 __device__ __forceinline__ double fast_rsqrt(const double x) {
+#ifdef SPARC_OW_FAKE
+    return x * 0.5;   // timing experiment
+#endif
     double y = __builtin_amdgcn_rsq(x);
     y = y * (1.5 - 0.5 * x * y * y);
     y = y * (1.5 - 0.5 * x * y * y);
@@ -161,6 +164,9 @@ __device__ __forceinline__ double fast_rsqrt(const double x) {
 
 // 1 / x in float64: the hardware estimate refined by two Newton steps
 __device__ __forceinline__ double fast_rcp(const double x) {
+#ifdef SPARC_OW_FAKE
+    return x * 0.25;   // timing experiment
+#endif
     double y = __builtin_amdgcn_rcp(x);
     y = y * (2.0 - x * y);
     y = y * (2.0 - x * y);
@@ -220,87 +226,76 @@ __device__ long long g_ow_stamps[8];   // developer timeline of orth_weights_ker
 
 // ---- blocked factorisations of a k x k LDS image, 16 columns at a time ------------------------------------------
 // A column-at-a-time factorisation costs a barrier and two LDS round trips per column (1200-1450 cycles each at
-// k = 47).  Here a 16 x 16 diagonal block is factored by ONE wave with a column of the block in the registers of
-// every lane (the pivot row reaches the other lanes through DPP broadcasts, no LDS, no barrier), the panels beside
+// k = 47).  Here a 16 x 16 diagonal block is factored by ONE wave with the block in its registers (a column's
+// elimination is one matrix instruction: no memory, no barrier), the panels beside
 // it are solved by one thread per column (or row) with the block's factor read from LDS (the same address in all
 // lanes: broadcast reads), and the trailing matrix is updated on the f64 matrix cores: three barriers per 16 columns.
 
-template <int J>
-__device__ __forceinline__ double bcast16(const double x) {   // lane J of the 16-lane DPP row, in every lane of the row
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + J, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + J, 0xf, 0xf, false);
+template <int L>
+__device__ __forceinline__ double readlane_d(const double x) {   // lane L of the wave, in every lane (through scalar registers)
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), L), hi = __builtin_amdgcn_readlane(__double2hiint(x), L);
     return __hiloint2double(hi, lo);
 }
 
-// trailing update of the block held in registers: d[i] -= l_i * u for i = I .. 15, l_i = lane I's `src` (Cholesky:
-// the scaled pivot row; LU: the multiplier column, passed per element)
-template <int J, int I>
-struct CholInner {
-    static __device__ __forceinline__ void run(double (&d)[16], const double fj) {
-        if constexpr (I < 16) {
-            d[I] -= bcast16<I>(fj) * fj;
-            CholInner<J, I + 1>::run(d, fj);
-        }
-    }
-};
+// The 16 x 16 diagonal block lives in the registers of ONE wave in the layout of the f64 matrix instruction's
+// accumulator: register q of lane (r = lane >> 4, c = lane & 15) is element (4 q + r, c).  A column's elimination is
+// then ONE v_mfma_f64_16x16x4 (a rank-one update through inner index r_J = J % 4, whose operands are exactly where
+// the pivot row already sits: the lanes of DPP row r_J, register J / 4), and the serial part of a step is the pivot
+// (read through scalar registers), its reciprocal and that instruction: no LDS, no barrier, ~35 instructions.
 
-// Cholesky (upper) of the 16 x 16 block in registers: lane c holds column c, d[i] = element (i, c) of the current
-// Schur complement for i <= c (what it holds below the diagonal is never used).  On return d[i] = F[i][c] for i <= c;
-// lane J < 16 of the wave writes rd[J] = 1 / F[J][J] (write: only one of the four 16-lane copies does);
-// bad = 1 + the first column whose pivot is not positive, else 0.
+// Cholesky (upper) of the symmetric block.  Step J: with u = e(J, :), rows below J take e(I, c) -= u_I u_c / pivot and
+// row J becomes the factor's row u / sqrt(pivot).  On return e holds F on and above the diagonal (below: not used);
+// lane J writes rd[J] = 1 / F[J][J]; bad = 1 + the first column whose pivot is not positive, else 0.
 template <int J>
-__device__ __forceinline__ void chol_block(double (&d)[16], double* rd, const int c, const bool write, int& bad) {
+__device__ __forceinline__ void chol_block(double4_t& e, double* rd, const int lane, int& bad) {
     if constexpr (J < 16) {
-        double piv = bcast16<J>(d[J]);
+        constexpr int qJ = J / 4, rJ = J % 4;
+        const bool src = (lane >> 4) == rJ;
+        double piv = readlane_d<rJ * 16 + J>(e[qJ]);
         if (!(piv > 0.0)) {
             if (!bad) bad = J + 1;
             piv = 1e-300;
         }
+        const double x = src ? e[qJ] : 0.0;                                      // B operand: u_c
+        const double y = (src && (lane & 15) > J) ? -x * fast_rcp(piv) : 0.0;    // A operand: -u_I / pivot, rows I > J only
+        e = __builtin_amdgcn_mfma_f64_16x16x4f64(y, x, e, 0, 0, 0);
         const double rs = fast_rsqrt(piv);
-        if (write && c == J) rd[J] = rs;
-        const double fj = d[J] * rs;
-        d[J] = fj;
-        CholInner<J, J + 1>::run(d, fj);
-#ifdef SPARC_OW_COLBAR
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-        chol_block<J + 1>(d, rd, c, write, bad);
+        if (src) e[qJ] = x * rs;
+        if (lane == J) rd[J] = rs;
+        chol_block<J + 1>(e, rd, lane, bad);
     }
 }
 
-template <int J, int I>
-struct LuInner {
-    static __device__ __forceinline__ void run(double (&d)[16], const double ip, const bool right, const bool mine) {
-        if constexpr (I < 16) {
-            if (mine) d[I] *= ip;                       // the multiplier column: lane J scales its own entries
-            const double l = bcast16<J>(d[I]);          // L[I][J]
-            if (right) d[I] -= l * d[J];                // columns right of the pivot: element (I, c) -= L[I][J] U[J][c]
-            LuInner<J, I + 1>::run(d, ip, right, mine);
-        }
-    }
-};
-
-// The sign-tracking LU of the 16 x 16 block in registers: lane c holds column c, d[a] = element (a, c).  Step J:
-// sgn = -sign(q_JJ) (the reference's Householder sign), pivot q_JJ - sgn, multipliers below it, update to the right.
-// On return the block holds U on and above the diagonal and the multipliers below; lane J writes the sign of column
-// J to sgn_out[J] (if that column exists: J < ncols) and the reciprocal pivot to rd[J].
+// The sign-tracking LU of the block, kept twice: e = the block, et = its transpose, so that column J (the
+// multipliers) is a ROW of et and sits in the same lanes as row J of e.  Step J: sgn = -sign(q_JJ) (the reference's
+// Householder sign), pivot q_JJ - sgn, l = column J / pivot, e -= l u^T and et -= u l^T (u = row J right of the
+// diagonal).  On return e holds U on and above the diagonal and the multipliers below; lane J writes the sign of
+// column J to sgn_out[J] (if that column exists: J < ncols) and the reciprocal pivot to rd[J].
 template <int J>
-__device__ __forceinline__ void lu_block(double (&d)[16], double* sgn_out, double* rd, const int c, const bool write,
+__device__ __forceinline__ void lu_block(double4_t& e, double4_t& et, double* sgn_out, double* rd, const int lane,
                                          const int ncols) {
     if constexpr (J < 16) {
-        const double qjj = bcast16<J>(d[J]);
+        constexpr int qJ = J / 4, rJ = J % 4;
+        const int r = lane >> 4, c = lane & 15;
+        const double qjj = readlane_d<rJ * 16 + J>(e[qJ]);
         const double sgn = qjj > 0.0 ? -1.0 : 1.0;
         const double ip = fast_rcp(qjj - sgn);
-        if (write && c == J) {
+        if (lane == J) {
             if (J < ncols) sgn_out[J] = sgn;
             rd[J] = ip;
         }
-        LuInner<J, J + 1>::run(d, ip, c > J, c == J);
-#ifdef SPARC_OW_COLBAR
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-        lu_block<J + 1>(d, sgn_out, rd, c, write, ncols);
+        const bool live = r == rJ && c > J;
+        const double x = live ? e[qJ] : 0.0;            // U[J][c], c > J
+        const double y = live ? et[qJ] * ip : 0.0;      // L[a][J], a > J (this lane's c is the row index a)
+        e = __builtin_amdgcn_mfma_f64_16x16x4f64(-y, x, e, 0, 0, 0);
+        et = __builtin_amdgcn_mfma_f64_16x16x4f64(-x, y, et, 0, 0, 0);
+        if (live) et[qJ] = y;                            // the multipliers, scaled, in both copies
+        if (c == J) {
+#pragma unroll
+            for (int q = qJ; q < 4; ++q)
+                if (4 * q + r > J) e[q] *= ip;
+        }
+        lu_block<J + 1>(e, et, sgn_out, rd, lane, ncols);
     }
 }
 
@@ -360,11 +355,34 @@ __global__ __launch_bounds__(OW_THREADS) void orth_weights_kernel(int64_t m, int
 #endif
     OW_STAMP(0)
     if (tid == 0) bad = 0;
+    // the kernel's reads from global memory are requested first (the Gram matrix; the top rows of Yt, which are not
+    // needed before the factor has been inverted) and land while the images are cleared
+    constexpr int PER = (SPARC_MAX_K * SPARC_MAX_K + OW_THREADS - 1) / OW_THREADS;
+    double gv[PER];
+    float tv[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int e = tid + u * OW_THREADS;
+        gv[u] = e < k * k ? G[e] : 0.0;
+        tv[u] = 0.f;
+        if (mode == 0 && e < k * k) {
+            const int64_t row = top_idx ? top_idx[e / k] : e / k;
+            if (row < m) tv[u] = Yt[row * ld + e % k];   // top rows of Yt
+        }
+    }
     zero_image(R, k);   // the products on the matrix cores read whole 16 x 16 tiles: zero beyond k
     zero_image(X, k);
     zero_image(Q, k);   // (the factor's image: its trailing updates read whole tiles too)
+    zero_image(T, k);
     __syncthreads();
-    for (int e = tid; e < k * k; e += OW_THREADS) R[(e / k) * KLD + e % k] = G[e];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int e = tid + u * OW_THREADS;
+        if (e < k * k) {
+            R[(e / k) * KLD + e % k] = gv[u];
+            T[(e / k) * KLD + e % k] = static_cast<double>(tv[u]);
+        }
+    }
     if (tid >= k && tid < (k + 15) / 16 * 16) R[tid * KLD + tid] = 1.0;   // identity beyond k: the last block stays regular
     __syncthreads();
 
@@ -375,17 +393,15 @@ __global__ __launch_bounds__(OW_THREADS) void orth_weights_kernel(int64_t m, int
     double* F = Q;
     const int ntile = (k + 15) / 16;
     for (int jb = 0; jb < k; jb += 16) {
-        if (tid < 64) {                                   // wave 0: the diagonal block, a column per lane (four copies)
-            const int c = tid & 15;
-            double d[16];
+        if (tid < 64) {                                   // wave 0: the diagonal block in its registers
+            const int r = tid >> 4, c = tid & 15;
+            double4_t e;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) d[i] = R[(jb + i) * KLD + jb + c];
+            for (int q = 0; q < 4; ++q) e[q] = R[(jb + 4 * q + r) * KLD + jb + c];
             int bd = 0;
-            chol_block<0>(d, rdiag + jb, c, tid < 16, bd);
-            if (tid < 16) {
+            chol_block<0>(e, rdiag + jb, tid, bd);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) F[(jb + i) * KLD + jb + c] = (i <= c) ? d[i] : 0.0;
-            }
+            for (int q = 0; q < 4; ++q) F[(jb + 4 * q + r) * KLD + jb + c] = (4 * q + r <= c) ? e[q] : 0.0;
             if (tid == 0 && bd && !bad) bad = jb + bd;
         }
         __syncthreads();
@@ -477,29 +493,22 @@ __global__ __launch_bounds__(OW_THREADS) void orth_weights_kernel(int64_t m, int
 
     OW_STAMP(3)
     if (mode == 0) {
-        zero_image(T, k);
-        __syncthreads();
-        for (int e = tid; e < k * k; e += OW_THREADS) {
-            const int i = e / k, j = e % k;
-            const int64_t row = top_idx ? top_idx[i] : i;
-            T[i * KLD + j] = row < m ? static_cast<double>(Yt[row * ld + j]) : 0.0;  // top rows of Yt
-        }
-        __syncthreads();
         mm_kk(k, T, false, X, false, Q, 1.0);   // Q = Yt[top] X
         OW_STAMP(4)
         // Householder signs from the modified LU of Q, in blocks of 16 columns: only the sign sequence is wanted.
         // (Q is zero beyond k; a zero diagonal there gives a pivot of 1 and no multipliers.)
         for (int jb = 0; jb < k; jb += 16) {
-            if (tid < 64) {                               // wave 0: the diagonal block, a column per lane
-                const int c = tid & 15;
-                double d[16];
+            if (tid < 64) {                               // wave 0: the diagonal block in its registers
+                const int r = tid >> 4, c = tid & 15;
+                double4_t e, et;
 #pragma unroll
-                for (int a = 0; a < 16; ++a) d[a] = Q[(jb + a) * KLD + jb + c];
-                lu_block<0>(d, sg + jb, rdiag + jb, c, tid < 16, k - jb);
-                if (tid < 16) {
-#pragma unroll
-                    for (int a = 0; a < 16; ++a) Q[(jb + a) * KLD + jb + c] = d[a];
+                for (int q = 0; q < 4; ++q) {
+                    e[q] = Q[(jb + 4 * q + r) * KLD + jb + c];
+                    et[q] = Q[(jb + c) * KLD + jb + 4 * q + r];
                 }
+                lu_block<0>(e, et, sg + jb, rdiag + jb, tid, k - jb);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Q[(jb + 4 * q + r) * KLD + jb + c] = e[q];
             }
             __syncthreads();
             if (jb + 16 >= k) break;

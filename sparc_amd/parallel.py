@@ -105,12 +105,16 @@ class LayerwiseReducer:
         flat = self._bucket(layer, n + db.numel(), dW)
         flat[:n].view(dW.shape).copy_(dW)              # a transposed view is laid out as the parameter on the way
         flat[n:].view(db.shape).copy_(db)
+        averaged = False
         if _staged(flat, self.group):          # gloo rehearsal on a GPU: through the host, synchronously
             all_reduce_sum(flat, self.group)
             work = None
+        elif dist.get_backend(self.group) == "nccl":   # RCCL averages inside the collective: no scaling kernel per bucket
+            work = dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+            averaged = True
         else:
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self.pending.append((layer, work, flat, dW.shape, db.shape))
+        self.pending.append((layer, work, flat, dW.shape, db.shape, averaged))
         return dW, db
 
     def finish(self) -> int:
@@ -119,10 +123,11 @@ class LayerwiseReducer:
         step's backward overwrites the bucket."""
         done = len(self.pending)
         self.reduced = {}
-        for layer, work, flat, w_shape, b_shape in self.pending:
+        for layer, work, flat, w_shape, b_shape, averaged in self.pending:
             if work is not None:
                 work.wait()
-            flat.div_(self.world)
+            if not averaged:
+                flat.div_(self.world)
             n = flat.numel() - int(np.prod(b_shape))
             gW, gb = flat[:n].view(w_shape), flat[n:].view(b_shape)
             self.reduced[layer] = (gW, gb)
