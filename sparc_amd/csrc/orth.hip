@@ -2,6 +2,8 @@
 // triangular inverse and Householder sign recovery in LDS, the product with the
 // orthonormalisation weights, and the backward of the whole chain.
 #include <mutex>
+#include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 
@@ -611,107 +613,66 @@ __global__ __launch_bounds__(OWB_THREADS) void orth_weights_bwd_kernel(int64_t m
     }
 }
 
-// Z = Yt H for a float64 H, accumulated in float64 (Z float32): the gradient with respect to the orthonormalisation
-// batch.  For an ill-conditioned batch the entries of H are many orders of magnitude larger than those of the
-// product (they cancel), so rounding H or the partial sums to float32 would cost the gradient its leading digits.
-// 64 rows per block; thread (tr, tc) owns the 4 x 4 outputs rows 4 tr.., columns 4 tc.. and walks the inner
-// dimension with one 16-byte LDS read of Yt (kept transposed) and one 32-byte read of H per step.
-__global__ __launch_bounds__(256) void orth_apply_f64_kernel(int64_t m, int k, const float* __restrict__ Yt, int64_t ld,
-                                                             const double* __restrict__ H, float* __restrict__ Z, int64_t ldz) {
-    __shared__ __attribute__((aligned(16))) double Hs[SPARC_MAX_K][SPARC_MAX_K];
-    __shared__ __attribute__((aligned(16))) float Ys[SPARC_MAX_K][64 + 4];   // [l][row]
-    const int tid = threadIdx.x;
-    const int64_t row0 = static_cast<int64_t>(blockIdx.x) * 64;
-    for (int e = tid; e < SPARC_MAX_K * SPARC_MAX_K; e += 256) {
-        const int i = e / SPARC_MAX_K, j = e % SPARC_MAX_K;
-        Hs[i][j] = (i < k && j < k) ? H[i * k + j] : 0.0;
-    }
-    for (int e = tid; e < 64 * k; e += 256) {
-        const int r = e / k, c = e % k;
-        Ys[c][r] = (row0 + r < m) ? Yt[(row0 + r) * ld + c] : 0.f;
-    }
-    __syncthreads();
-    const int tr = tid >> 4, tc = tid & 15;
-    if (tc * 4 >= k) return;
-    double acc[4][4];
+// Z[rows] = Yt[rows] W on the matrix cores, one wavefront per tile of 16 rows: W (k x k, zero padded to 16 NT) sits in
+// registers in the B-operand layout (lane (kk = lane >> 4, i = lane & 15) holds W[4 s + kk][16 t + i]), the 16 rows of
+// Yt are read straight from global memory in the A-operand layout (lane (kk, i): row i, columns 4 s + kk; the 16-byte
+// pieces of a row are consumed by the four kk groups of the same load), no LDS, no barrier.
+//   F64 = false: W = Wo or Wo^T in float32 (v_mfma_f32_16x16x4): SpectralNetModel.forward's Y = Yt Wo and its backward.
+//   F64 = true:  W = H in float64, Yt widened, sums in float64 (v_mfma_f64_16x16x4), Z float32: the gradient with
+//                respect to the orthonormalisation batch.  For an ill-conditioned batch the entries of H are many
+//                orders of magnitude larger than those of the product (they cancel), so rounding H or the partial
+//                sums to float32 would cost the gradient its leading digits.
+typedef float float4_t __attribute__((ext_vector_type(4)));
+template <int NT, bool F64>
+__global__ __launch_bounds__(256) void orth_apply_mfma(int64_t m, int k, const float* __restrict__ Yt, int64_t ld,
+                                                       const void* __restrict__ Wv, int transpose_w,
+                                                       float* __restrict__ Z, int64_t ldz) {
+    constexpr int S = 4 * NT;   // inner steps of four
+    typedef typename std::conditional<F64, double, float>::type T;
+    typedef typename std::conditional<F64, double4_t, float4_t>::type Acc;
+    const int lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4;
+    T b[NT][S];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
-    for (int l = 0; l < k; ++l) {
-        const float4 y = *reinterpret_cast<const float4*>(&Ys[l][tr * 4]);
-        const double2 h0 = *reinterpret_cast<const double2*>(&Hs[l][tc * 4]);
-        const double2 h1 = *reinterpret_cast<const double2*>(&Hs[l][tc * 4 + 2]);
-        const double yv[4] = {static_cast<double>(y.x), static_cast<double>(y.y), static_cast<double>(y.z), static_cast<double>(y.w)};
-        const double hv[4] = {h0.x, h0.y, h1.x, h1.y};
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] += yv[i] * hv[j];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t row = row0 + tr * 4 + i;
-        if (row < m) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (tc * 4 + j < k) Z[row * ldz + tc * 4 + j] = static_cast<float>(acc[i][j]);
-        }
-    }
-}
-
-// Z[rows] = Yt[rows] Wo  (or Wo^T).  64 rows per block; thread (tr, tc) owns the 4 x 4 outputs
-// rows 4 tr.., columns 4 tc.. and walks the inner dimension with one 16-byte LDS read of Wo per step.
-template <int KP>
-__global__ __launch_bounds__(256) void orth_apply_kernel(int64_t m, int k, const float* __restrict__ Yt, int64_t ld,
-                                                         const float* __restrict__ Wo, int transpose_w,
-                                                         float* __restrict__ Z, int64_t ldz) {
-    constexpr int TC = KP / 4;
-    __shared__ __attribute__((aligned(16))) float Ws[KP][KP];
-    __shared__ float Ys[64][KP + 1];
-    const int tid = threadIdx.x;
-    for (int e = tid; e < KP * KP; e += 256) {
-        const int i = e / KP, j = e % KP;
-        float w = 0.f;
-        if (i < k && j < k) w = transpose_w ? Wo[j * k + i] : Wo[i * k + j];
-        Ws[i][j] = w;
-    }
-    const int64_t r0 = static_cast<int64_t>(blockIdx.x) * 64;
-    for (int e = tid; e < 64 * KP; e += 256) {
-        const int r = e / KP, c = e % KP;
-        const int64_t row = r0 + r;
-        Ys[r][c] = (row < m && c < k) ? Yt[row * ld + c] : 0.f;
-    }
-    __syncthreads();
-    if (tid >= 16 * TC) return;
-    const int tr = tid / TC, tc = tid % TC;
-    float acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-#pragma unroll 4
-    for (int l = 0; l < KP; ++l) {
-        const float4 w = *reinterpret_cast<const float4*>(&Ws[l][4 * tc]);
-        const float y[4] = {Ys[4 * tr][l], Ys[4 * tr + 1][l], Ys[4 * tr + 2][l], Ys[4 * tr + 3][l]};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            acc[i][0] = fmaf(y[i], w.x, acc[i][0]);
-            acc[i][1] = fmaf(y[i], w.y, acc[i][1]);
-            acc[i][2] = fmaf(y[i], w.z, acc[i][2]);
-            acc[i][3] = fmaf(y[i], w.w, acc[i][3]);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t row = r0 + 4 * tr + i;
-        if (row < m) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = 4 * tc + j;
-                if (c < k) Z[row * ldz + c] = acc[i][j];
+        for (int s_ = 0; s_ < S; ++s_) {
+            const int l = 4 * s_ + kk, c = 16 * t + i;
+            T w = 0;
+            if (l < k && c < k) {
+                if (F64) w = static_cast<const double*>(Wv)[l * k + c];
+                else w = transpose_w ? static_cast<const float*>(Wv)[c * k + l] : static_cast<const float*>(Wv)[l * k + c];
             }
+            b[t][s_] = w;
         }
+    const int64_t ntiles = (m + 15) / 16;
+    const int64_t nwaves = static_cast<int64_t>(gridDim.x) * 4;
+    for (int64_t rt = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6); rt < ntiles; rt += nwaves) {
+        const int64_t row = rt * 16 + i;
+        T a[S];
+#pragma unroll
+        for (int s_ = 0; s_ < S; ++s_) {
+            const int l = 4 * s_ + kk;
+            a[s_] = (row < m && l < k) ? static_cast<T>(Yt[row * ld + l]) : static_cast<T>(0);
+        }
+        Acc acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = Acc{0, 0, 0, 0};
+#pragma unroll
+        for (int s_ = 0; s_ < S; ++s_)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if constexpr (F64) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s_], b[t][s_], acc[t], 0, 0, 0);
+                else acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s_], b[t][s_], acc[t], 0, 0, 0);
+            }
+        // result register q of a lane: row kk + 4 q (f64 instruction) or 4 kk + q (f32 instruction), column i
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t r = rt * 16 + (F64 ? kk + 4 * q : 4 * kk + q);
+                const int c = 16 * t + i;
+                if (r < m && c < k) Z[r * ldz + c] = static_cast<float>(acc[t][q]);
+            }
     }
 }
 
@@ -720,6 +681,19 @@ int gram_blocks(int64_t m) {
     if (nb > GRAM_MAX_BLOCKS) nb = GRAM_MAX_BLOCKS;
     if (nb < 1) nb = 1;
     return static_cast<int>(nb);
+}
+
+template <bool F64>
+int launch_orth_apply(int64_t m, int k, const float* Yt, int64_t ld, const void* W, int transpose_w, float* Z, int64_t ldz,
+                      hipStream_t stream) {
+    const int64_t ntiles = (m + 15) / 16;
+    const dim3 g(static_cast<unsigned>(std::min<int64_t>((ntiles + 3) / 4, 1024))), b(256);
+    if (k <= 16) hipLaunchKernelGGL((orth_apply_mfma<1, F64>), g, b, 0, stream, m, k, Yt, ld, W, transpose_w, Z, ldz);
+    else if (k <= 32) hipLaunchKernelGGL((orth_apply_mfma<2, F64>), g, b, 0, stream, m, k, Yt, ld, W, transpose_w, Z, ldz);
+    else if (k <= 48) hipLaunchKernelGGL((orth_apply_mfma<3, F64>), g, b, 0, stream, m, k, Yt, ld, W, transpose_w, Z, ldz);
+    else hipLaunchKernelGGL((orth_apply_mfma<4, F64>), g, b, 0, stream, m, k, Yt, ld, W, transpose_w, Z, ldz);
+    SPARC_CHECK_LAUNCH();
+    return SPARC_OK;
 }
 
 }  // namespace
@@ -831,21 +805,13 @@ extern "C" int sparc_orth_weights_bwd_f64(int64_t m, int k, const double* gWo, c
 extern "C" int sparc_orth_apply_f64(int64_t m, int k, const float* Yt, int64_t ld, const double* H, float* Z, int64_t ldz,
                                     sparc_stream_t stream) {
     if (m <= 0 || k < 1 || k > SPARC_MAX_K || !Yt || !H || !Z || ld < k || ldz < k) return SPARC_ERR_ARG;
-    hipLaunchKernelGGL(orth_apply_f64_kernel, dim3(static_cast<unsigned>((m + 63) / 64)), dim3(256), 0, stream, m, k, Yt, ld, H, Z, ldz);
-    SPARC_CHECK_LAUNCH();
-    return SPARC_OK;
+    return launch_orth_apply<true>(m, k, Yt, ld, H, 0, Z, ldz, stream);
 }
 
 extern "C" int sparc_orth_apply(int64_t m, int k, const float* Yt, int64_t ld, const float* Wo, int transpose_w,
                                 float* Z, int64_t ldz, sparc_stream_t stream) {
     if (m <= 0 || k < 1 || k > SPARC_MAX_K || !Yt || !Wo || !Z || ld < k || ldz < k) return SPARC_ERR_ARG;
-    const dim3 g(static_cast<unsigned>((m + 63) / 64)), b(256);
-    if (k <= 16) hipLaunchKernelGGL((orth_apply_kernel<16>), g, b, 0, stream, m, k, Yt, ld, Wo, transpose_w, Z, ldz);
-    else if (k <= 32) hipLaunchKernelGGL((orth_apply_kernel<32>), g, b, 0, stream, m, k, Yt, ld, Wo, transpose_w, Z, ldz);
-    else if (k <= 48) hipLaunchKernelGGL((orth_apply_kernel<48>), g, b, 0, stream, m, k, Yt, ld, Wo, transpose_w, Z, ldz);
-    else hipLaunchKernelGGL((orth_apply_kernel<64>), g, b, 0, stream, m, k, Yt, ld, Wo, transpose_w, Z, ldz);
-    SPARC_CHECK_LAUNCH();
-    return SPARC_OK;
+    return launch_orth_apply<false>(m, k, Yt, ld, Wo, transpose_w, Z, ldz, stream);
 }
 
 #ifdef SPARC_OW_STAMPS
