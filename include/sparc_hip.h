@@ -199,7 +199,7 @@ int sparc_spmm(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* col
  * chunks that get a wavefront each, and the chunks' partial sums are added in chunk order (with the row's X0), so
  * a hub row no longer keeps one wavefront busy long after the rest of the launch has drained, and the result does
  * not depend on the schedule.  The reference has no sparse product at all (it multiplies the dense m x m matrices,
- * src/SpectralTrainer.py:289); this is the whole-graph product of BASELINE config 5 (R-MAT, 10 M nodes).
+ * src/SpectralTrainer.py:289); this is the whole-graph product of the SpMM roofline stress case (R-MAT graph, 10 M nodes, 500 M edges, k = 64).
  * The caller supplies the plan, all device arrays: long_row[nlong], the rows above the limit; the chunks of
  * long_row[i] are c in [long_first[i], long_first[i + 1]) (long_first has nlong + 1 entries, long_first[nlong] ==
  * nchunks) and chunk c covers the stored entries [chunk_begin[c], chunk_end[c]), which together are exactly the

@@ -994,7 +994,7 @@ def test_facade_fit_predict_with_autoencoder(dev, golden, tmp_path, monkeypatch,
 
 # ---------------------------------------------------------------- real graph: Cora through the reference's loader
 def test_cora_batch_matches_reference(dev, golden):
-    """BASELINE config 1's graph (m = 2437, 11 041 stored entries, off-diagonal weight 2, k = 64): support built
+    """The shipped Cora graph (m = 2437, 11 041 stored entries, off-diagonal weight 2, k = 64): support built
     on the device bit-exact, affinity sums, orthonormalisation weights, embedding, both loss branches and the
     gradient against the imported reference (tools/gen_golden_cora.py)."""
     from sparc_amd import utils as U

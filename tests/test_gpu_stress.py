@@ -1,4 +1,4 @@
-"""The plain whole-graph product Z = A X (the SpMM roofline stress of BASELINE config 5) at a size SciPy
+"""The plain whole-graph product Z = A X (the SpMM roofline stress case: an R-MAT graph of 10 M nodes and 500 M edges at full size) at a size SciPy
 checks in a second: a scaled-down R-MAT graph (same quadrant probabilities, power-law degrees, hub rows
 of thousands of entries) in natural order and relabelled by decreasing degree, through the C ABI."""
 import ctypes
