@@ -172,7 +172,17 @@ def spawn_ranks(n: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
-def check_launch(world: int, rank: int, local_rank: int, backend: str) -> None:
+def keep_stdout_for_the_result():
+    """Libraries under the ranks write to file descriptor 1 themselves (RCCL prints its version banner there when the
+    first communicator forms).  Point descriptor 1 at stderr for the rest of the process and return a file on the
+    original stdout: the result line written to it is then the only thing stdout carries."""
+    sys.stdout.flush()
+    result = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return result
+
+
+def check_launch(world: int, rank: int, local_rank: int, backend: str, result=sys.stdout) -> None:
     """--check-launch: the ranks meet, sum their rank numbers and rank 0 reports what it saw; no kernel runs.  On a
     host without a GPU the group is formed over gloo."""
     has_gpu = torch.cuda.is_available()
@@ -192,7 +202,7 @@ def check_launch(world: int, rank: int, local_rank: int, backend: str) -> None:
         seen = 1
     if rank == 0:
         print(json.dumps({"launch_check": {"world": seen, "env_world": world, "backend": backend if world > 1 else None,
-                                           "rank_sum": float(total[0]), "device": str(dev)}}), flush=True)
+                                           "rank_sum": float(total[0]), "device": str(dev)}}), file=result, flush=True)
 
 
 def main():
@@ -224,8 +234,9 @@ def main():
                          f"--nproc-per-node {args.gpus}, or leave WORLD_SIZE unset and bench.py starts them itself")
     # rehearsal knobs for a one-GPU box: several ranks on one card over gloo (never used by the driver)
     backend = os.environ.get("SPARC_BENCH_BACKEND", "nccl")
+    result = keep_stdout_for_the_result()
     if args.check_launch:
-        return check_launch(world, rank, local_rank, backend)
+        return check_launch(world, rank, local_rank, backend, result)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
     if "SPARC_BENCH_DEVICE" in os.environ:
@@ -263,7 +274,17 @@ def main():
     if not mine:
         raise SystemExit(f"rank {rank} is left without a batch: the graph has {len(nodes_of)} batches for {world} ranks "
                          f"(raise --scale)")
-    trainer = ShardedSpectralTrainer(arch, din, dev, lr=1e-3, seed=0, hip_graph=args.hip_graph)
+    # SPARC_BENCH_REDUCE_ALONE=1 (rehearsal knob, never used by the driver): one rank forms an RCCL group of its own and
+    # runs the data-parallel step's bucket copies and collectives, which shows their cost on a one-GPU box
+    alone = world == 1 and os.environ.get("SPARC_BENCH_REDUCE_ALONE") == "1"
+    if alone:
+        import socket
+        s_ = socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+        s_.close()
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    trainer = ShardedSpectralTrainer(arch, din, dev, lr=1e-3, seed=0, hip_graph=args.hip_graph, reduce_in_a_world_of_one=alone)
     t0 = time.perf_counter()
     for b in mine:
         pt = nodes_of[b]
@@ -385,9 +406,10 @@ def main():
                                                full_nodes=int(np.mean(ms)))
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=result, flush=True)
     if world > 1:
         dist.barrier()
+    if world > 1 or alone:
         dist.destroy_process_group()
 
 

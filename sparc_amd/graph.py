@@ -439,6 +439,33 @@ class ClusterBatch:
         delta = torch.where(has_diag, diag - r, torch.zeros_like(r))
         return torch.stack([r, delta, delta / r, 1.0 / r], dim=1).contiguous()
 
+    # class-wide switch (measurements, tools/run_parity_exp.sh): a row's in-window entries ordered by operand-row parity.
+    # Off: it takes 70 % of the LDS bank conflicts of the dual-width kernel away (SQ_LDS_BANK_CONFLICT 658 k -> 198 k
+    # cycles per launch, SQ_LDS_IDX_ACTIVE 2.25 M -> 1.79 M) and the kernel takes as long as before.
+    tile_parity_order = False
+
+    def _parity_order(self, row, wcol, inside, ein, g, r_p0):
+        """A new place inside its row's in-window entries for every stored entry (the other entries keep `ein`).
+        With two floats per lane an operand row of the LDS window covers half of the 64 banks, the half chosen by
+        the parity of its index in the window, and one ds_read_b64 serves two DPP rows (two matrix rows of a slot)
+        per LDS cycle: they collide when their operand rows have the same parity.  Matrix rows on even DPP rows
+        therefore take their even operand rows first, those on odd DPP rows their odd ones: the t-th entries of the
+        two rows then differ in parity except where the counts do not match."""
+        odd = (wcol & 1).bool()
+        is_e, is_o = inside & ~odd, inside & odd
+        ce, co = torch.cumsum(is_e, 0), torch.cumsum(is_o, 0)
+        zero = torch.zeros(1, dtype=ce.dtype, device=ce.device)
+        start = r_p0[row]                                   # first stored entry of the row
+        be = torch.cat([zero, ce])[start]                   # evens / odds stored before the row begins
+        bo = torch.cat([zero, co])[start]
+        rank_e, rank_o = ce - 1 - be, co - 1 - bo           # place among the row's evens / odds (where it is one)
+        m = self.m
+        ne = torch.zeros(m, dtype=ce.dtype, device=ce.device).scatter_add_(0, row, is_e.to(ce.dtype))
+        no = torch.zeros(m, dtype=ce.dtype, device=ce.device).scatter_add_(0, row, is_o.to(ce.dtype))
+        evens_first = (g & 1) == 0
+        new = torch.where(evens_first, torch.where(is_e, rank_e, ne[row] + rank_o), torch.where(is_o, rank_o, no[row] + rank_e))
+        return torch.where(inside, new, ein)
+
     def _plan(self, vec, kp, n_slabs, dual, threads, target, mirrored=False, pattern=False):
         """Tiling for one kernel geometry: work descriptors and slot records (planned on the host) and the
         entry streams in consumption order (scattered on the device).  mirrored: bake the mirrored values
@@ -477,10 +504,12 @@ class ClusterBatch:
         ein = e - r_nb[row]
         inside = (ein >= 0) & (ein < r_ni[row])
         g, lng = r_g[row], r_long[row]
+        col = self.colidx.to(torch.int64)
+        if self.tile_parity_order and vec == 2:
+            ein = torch.where(lng, ein, self._parity_order(row, col - r_w0[row], inside, ein, g, r_p0))
         pos_in = r_base[row] + torch.where(lng, ein, (torch.div(ein, 4, rounding_mode="floor") * 4 + g) * 4 + ein % 4)
         t = torch.where(ein < 0, e, e - r_ni[row])
         pos_out = r_obase[row] + torch.where(lng, t, t * 4 + g)
-        col = self.colidx.to(torch.int64)
         valT = self.valT if self.valT is not None else self.val
         v_main, v_mirr = (valT, self.val) if mirrored else (self.val, valT)
         n_s, n_o = pl["stream_len"] + 16, pl["ostream_len"] + 16

@@ -145,7 +145,7 @@ class ShardedSpectralTrainer:
 
     def __init__(self, architecture: dict, input_dim: int, device, lr: float = 1e-3, orth_mode: str = "reference",
                  group=None, seed: Optional[int] = 0, net=None, criterion=None, fused_adam: bool = True,
-                 hip_graph: bool = False):
+                 hip_graph: bool = False, reduce_in_a_world_of_one: bool = False):
         self.device = torch.device(device)
         if seed is not None:
             torch.manual_seed(seed)  # identical initial weights on every rank
@@ -158,7 +158,10 @@ class ShardedSpectralTrainer:
         self.net = net
         self.k = architecture["output_dim"]
         self.group = group
-        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        # reduce_in_a_world_of_one: run the bucket copies and the collectives even with a single rank (a measurement of
+        # what the data-parallel step adds on one GPU; the result is the single-process step)
+        self.distributed = dist.is_available() and dist.is_initialized() and \
+            (dist.get_world_size(group) > 1 or reduce_in_a_world_of_one)
         if self.distributed:
             for p in self.net.parameters():
                 broadcast(p.data, 0, group)

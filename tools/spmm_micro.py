@@ -23,6 +23,7 @@ k = int(os.environ.get("K", k))
 ClusterBatch.tile_vec = int(os.environ.get("VEC", "0")) or None
 ClusterBatch.tile_threads = int(os.environ.get("THREADS", "0")) or None
 ClusterBatch.tile_target_wgs = int(os.environ.get("WGS", "0")) or None
+ClusterBatch.tile_parity_order = os.environ.get("PARITY", "0") == "1"
 p0, lo, hi, p1 = b._in_window_ranges()
 n_out = (lo - p0) + (p1 - hi)
 t = b.tiling(k, True)
