@@ -242,6 +242,15 @@ int sparc_profile_end(double* total_ms, int64_t* launches);
 size_t sparc_gram_workspace_bytes(int64_t m, int k);
 int sparc_gram(int64_t m, int k, const float* A, int64_t lda, const float* B, int64_t ldb,
                double* G, void* ws, size_t ws_bytes, sparc_stream_t stream);
+/* sparc_gram and sparc_orth_apply on the second matrix in one launch: G = A^T B and Z = B W (transpose_w = 0) or B W^T (1),
+ * W float [k][k], Z float [m][ldz].  The backward of Y = Yt Wo (src/SpectralTrainer.py:103 under loss.backward(), :237)
+ * needs both from the same pair: d Wo = Yt^T gY and d Yt = gY Wo^T.  Bitwise the results of the two separate calls. */
+int sparc_gram_apply(int64_t m, int k, const float* A, int64_t lda, const float* B, int64_t ldb, double* G,
+                     const float* W, int transpose_w, float* Z, int64_t ldz, void* ws, size_t ws_bytes,
+                     sparc_stream_t stream);
+/* G = the sum of nparts partial Gram matrices double [nparts][k][k], in a fixed order (the second half of sparc_gram,
+ * for producers that leave the partial matrices themselves: sparc_linear_narrow_fwd_gram). */
+int sparc_gram_reduce(int k, int nparts, const double* partials, double* G, sparc_stream_t stream);
 /* sparc_gram without a workspace argument and without any allocation.  No counterpart in the
  * reference: it is for callers that cannot allocate device memory or carry a workspace (code
  * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  Same kernels,
@@ -287,9 +296,9 @@ int sparc_orth_apply_f64(int64_t m, int k, const float* Yt, int64_t ld, const do
  *                     output layer (f32 MFMA, fixed summation order).
  * sparc_first_layer_bwd: the whole backward of the first Linear+ReLU layer (its input needs no
  *                     gradient) in one pass over g and h [m][n], n a multiple of 64, 16-byte aligned
- *                     rows: with gp = g * [h > 0] (never written out), dWt_db [din+1][n] receives
- *                     x^T gp (the transposed weight gradient, x [m][din], din < SPARC_MAX_K) in rows
- *                     0..din-1 and the bias gradient, the column sums of gp, in row din.
+ *                     rows: with gp = g * [h > 0] (never written out), dW_db receives gp^T x, the weight
+ *                     gradient [n][din] in the layout of the layer's weight (x [m][din], din < SPARC_MAX_K),
+ *                     and behind it the bias gradient [n], the column sums of gp: (din + 1) n floats.
  * sparc_linear_narrow_fwd: out = act(x W^T + b) for the narrow output layer: x [m][K], K a multiple of
  *                     16 with 16-byte aligned rows, W [n_out][K], n_out <= SPARC_MAX_K and
  *                     16 (n_out rounded up to 16) (K + 4) floats within 150 KB of LDS; act 0 ReLU,
@@ -306,17 +315,28 @@ int sparc_wgrad_small(int64_t m, int n_out, int n_in, const float* g, int64_t ld
                       float* dW, void* ws, size_t ws_bytes, sparc_stream_t stream);
 size_t sparc_first_layer_bwd_workspace_bytes(int din, int n);
 int sparc_first_layer_bwd(int64_t m, int din, int n, const float* x, int64_t ldx, const float* g, int64_t ldg,
-                          const float* h, int64_t ldh, float* dWt_db, void* ws, size_t ws_bytes, sparc_stream_t stream);
+                          const float* h, int64_t ldh, float* dW_db, void* ws, size_t ws_bytes, sparc_stream_t stream);
 /* The same without reading the layer's activations h: for a layer of at most 16 inputs whose forward was
  * sparc_linear_narrow_in_fwd, the sign of every pre-activation is recomputed from x, W [n][din] and b [n] with that
  * kernel's own sequence of fused multiply-adds (bit for bit the forward's value), which halves the traffic of the
  * pass.  Same part of the reference's backward as sparc_first_layer_bwd (autograd of src/SpectralTrainer.py:28-39
  * through loss.backward(), :237). */
 int sparc_first_layer_bwd_recompute(int64_t m, int din, int n, const float* x, int64_t ldx, const float* g,
-                                    int64_t ldg, const float* W, const float* b, float* dWt_db, void* ws,
+                                    int64_t ldg, const float* W, const float* b, float* dW_db, void* ws,
                                     size_t ws_bytes, sparc_stream_t stream);
 int sparc_linear_narrow_fwd(int64_t m, int K, int n_out, int act, const float* x, int64_t ldx, const float* W,
                             const float* b, float* out, int64_t ldo, sparc_stream_t stream);
+/* sparc_linear_narrow_fwd that also returns G = out[:gram_rows]^T out[:gram_rows] (double [n_out][n_out]): in a training
+ * step the output layer's result for the orthogonality batch goes straight into the Gram matrix of
+ * _make_orthonorm_weights (src/SpectralTrainer.py:96-97 then :62), and a wave's output tile sits in registers in the
+ * layout the f64 matrix instruction takes, so the product rides in the forward's epilogue (bitwise the same `out`;
+ * G sums the same products as sparc_gram in another fixed order).  1 <= gram_rows <= m; ws: the query's bytes,
+ * 256-byte aligned (one partial matrix per workgroup).  Every wave takes one tile of 16 rows and every CU one
+ * workgroup: m beyond 65536 rows (32768 for n_out > 48) returns SPARC_ERR_SIZE and the caller makes the two calls. */
+size_t sparc_linear_narrow_fwd_gram_workspace_bytes(int n_out);
+int sparc_linear_narrow_fwd_gram(int64_t m, int K, int n_out, int act, const float* x, int64_t ldx, const float* W,
+                                 const float* b, float* out, int64_t ldo, int64_t gram_rows, double* G, void* ws,
+                                 size_t ws_bytes, sparc_stream_t stream);
 size_t sparc_dgrad_narrow_relu_workspace_bytes(int64_t m, int N);
 int sparc_dgrad_narrow_relu(int64_t m, int n_out, int N, const float* g, int64_t ldg, const float* W,
                             const float* hprev, int64_t ldh, float* dx, int64_t ldx, float* db_prev,

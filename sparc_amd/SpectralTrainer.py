@@ -23,7 +23,7 @@ import torch.optim as optim
 
 from .graph import ClusterBatch, require_gpu
 from .ops import (ACT_RELU, ACT_TANH, ORTH_CHOLESKY, ORTH_REFERENCE, LapLoss, LinearAct, OrthApply, OrthPair, OrthWeights,
-                  SpectralMLP, SplitRows)
+                  SpectralMLP, SpectralMLPGram, SplitRows)
 
 
 class SpectralNetModel(nn.Module):
@@ -56,14 +56,19 @@ class SpectralNetModel(nn.Module):
         matrix.  top_idx: the rows that lead the reference's (permuted) batch; default 0..k-1."""
         return OrthWeights.apply(Y, top_idx, self.orth_mode)
 
-    def embed_pre_orth(self, x: torch.Tensor) -> torch.Tensor:
+    def embed_pre_orth(self, x: torch.Tensor, gram_rows: int = 0):
+        """The MLP's output for the rows of x.  gram_rows > 0: (output, G) with G = output[:gram_rows]^T output[:gram_rows]
+        in float64 when the output layer's kernel took the product along, None otherwise."""
         kinds = [isinstance(layer[1], nn.Tanh) for layer in self.layers]
         if kinds[-1] and not any(kinds[:-1]) and x.dtype == torch.float32:   # ReLU ... ReLU, Tanh: the fused MLP
             params = [p for layer in self.layers for p in (layer[0].weight, layer[0].bias)]
+            if gram_rows > 0:
+                y, G = SpectralMLPGram.apply(x.contiguous(), self.grad_ready_hook, gram_rows, *params)
+                return y, (G if G.numel() else None)
             return SpectralMLP.apply(x.contiguous(), self.grad_ready_hook, *params)
         for layer, is_tanh in zip(self.layers, kinds):
             x = LinearAct.apply(x, layer[0].weight, layer[0].bias, ACT_TANH if is_tanh else ACT_RELU)
-        return x
+        return (x, None) if gram_rows > 0 else x
 
     def forward(self, x: torch.Tensor, should_update_orth_weights: bool = True, top_idx=None) -> torch.Tensor:
         Y_tilde = self.embed_pre_orth(x)
@@ -76,12 +81,14 @@ class SpectralNetModel(nn.Module):
         of the MLP over both batches: the parameters do not change between them, so the rows are the
         same; the orthonormalisation weights come from x_orth's rows and are applied to x_grad's."""
         m2, m1 = x_orth.shape[0], x_grad.shape[0]
-        Yt = self.embed_pre_orth(torch.cat([x_orth, x_grad], dim=0))
         if m2 == 0 or m1 == 0:
+            Yt = self.embed_pre_orth(torch.cat([x_orth, x_grad], dim=0))
             Yt_orth, Yt_grad = SplitRows.apply(Yt, m2)
             self.orthonorm_weights = self._make_orthonorm_weights(Yt_orth, top_idx)
             return OrthApply.apply(Yt_grad, self.orthonorm_weights)
-        Y, self.orthonorm_weights = OrthPair.apply(Yt, m2, top_idx, self.orth_mode)   # one graph node for both parts
+        # the Gram matrix of the orthogonality batch's rows comes out of the output layer's launch
+        Yt, G = self.embed_pre_orth(torch.cat([x_orth, x_grad], dim=0), gram_rows=m2)
+        Y, self.orthonorm_weights = OrthPair.apply(Yt, m2, top_idx, self.orth_mode, G)   # one graph node for both parts
         return Y
 
     def set_rotation_matrix(self, rotation_matrix):
@@ -293,7 +300,7 @@ class SpectralTrainer:
                 Y = self.spectral_net.forward_pair(feats[pid_2], feats[pid], top_idx=perm_2[:k])
                 W = self._get_valid_affinity_matrix(sup[pid], feats[pid])
                 loss = self.criterion(W, Y, is_normalized=True)
-                loss.backward()
+                loss.backward(gradient=LapLoss.unit_gradient(loss))
                 if reducer is not None and reducer.finish() == 0:
                     from .parallel import all_reduce_mean_gradients
                     all_reduce_mean_gradients(list(self.spectral_net.parameters()))
@@ -307,7 +314,7 @@ class SpectralTrainer:
                     Y = self.spectral_net(vfeats[pid], should_update_orth_weights=False)
                     W = self._get_valid_affinity_matrix(vsup[pid], vfeats[pid])
                     valid_loss += self.criterion(W, Y, is_normalized=True)
-            failed = OrthWeights.worst_info.get(torch.device(self.device).index or 0)
+            failed = OrthWeights.worst(self.device)
             n_steps = steps
             if world > 1:     # one small collective per epoch: both loss sums and the failure flag of every rank
                 packed = torch.stack([train_loss, valid_loss, (failed.double().reshape(()) if failed is not None
@@ -315,7 +322,7 @@ class SpectralTrainer:
                 all_reduce_sum(packed)
                 train_loss, valid_loss = packed[0], packed[1]
                 if failed is not None:
-                    failed.fill_(int(packed[2] != 0))
+                    OrthWeights.set_worst(self.device, int(packed[2] != 0))
                 n_steps = steps * world
             train_loss, valid_loss = float(train_loss), float(valid_loss)  # the epoch's only host sync
             if OrthWeights.check_and_reset(self.device) != 0:   # any step of the epoch, not only the last

@@ -65,6 +65,8 @@ _SIGS = {
     "sparc_gram_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "sparc_gram": (c_int, [c_int64, c_int, P, c_int64, P, c_int64, P, P, c_size_t, P]),
     "sparc_gram_static": (c_int, [c_int64, c_int, P, c_int64, P, c_int64, P, P]),
+    "sparc_gram_reduce": (c_int, [c_int, c_int, P, P, P]),
+    "sparc_gram_apply": (c_int, [c_int64, c_int, P, c_int64, P, c_int64, P, P, c_int, P, c_int64, P, c_size_t, P]),
     "sparc_orth_weights": (c_int, [c_int64, c_int, P, P, c_int64, P, c_int, P, P, P, P, P, P]),
     "sparc_orth_apply": (c_int, [c_int64, c_int, P, c_int64, P, c_int, P, c_int64, P]),
     "sparc_orth_weights_bwd": (c_int, [c_int64, c_int, P, P, P, P, c_int, P, P]),
@@ -78,6 +80,8 @@ _SIGS = {
     "sparc_first_layer_bwd": (c_int, [c_int64, c_int, c_int, P, c_int64, P, c_int64, P, c_int64, P, P, c_size_t, P]),
     "sparc_first_layer_bwd_recompute": (c_int, [c_int64, c_int, c_int, P, c_int64, P, c_int64, P, P, P, P, c_size_t, P]),
     "sparc_linear_narrow_fwd": (c_int, [c_int64, c_int, c_int, c_int, P, c_int64, P, P, P, c_int64, P]),
+    "sparc_linear_narrow_fwd_gram_workspace_bytes": (c_size_t, [c_int]),
+    "sparc_linear_narrow_fwd_gram": (c_int, [c_int64, c_int, c_int, c_int, P, c_int64, P, P, P, c_int64, c_int64, P, P, c_size_t, P]),
     "sparc_linear_narrow_in_fwd": (c_int, [c_int64, c_int, c_int, c_int, P, c_int64, P, P, P, c_int64, P]),
     "sparc_dgrad_narrow_relu_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "sparc_dgrad_narrow_relu": (c_int, [c_int64, c_int, c_int, P, c_int64, P, P, c_int64, P, c_int64, P, P, c_size_t, P]),

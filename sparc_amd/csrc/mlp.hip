@@ -278,9 +278,11 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(int64_t m, int n_out, 
     }
 }
 
-// dW[i][j] = sum over the chunks of partial[chunk][i][j]
+// dW[i][j] = sum over the chunks of partial[chunk][i][j].  t_rows > 0 (the first layer's backward, n_out = t_rows + 1):
+// rows 0 .. t_rows-1 are stored transposed, dW[j][i] as [n_in][t_rows] (the layout of the layer's weight), and row
+// t_rows (the bias gradient) behind them.
 __global__ __launch_bounds__(256) void wgrad_finish(int nchunks, int n_out, int n_out_pad, int n_in,
-                                                    const float* __restrict__ partial, float* __restrict__ dW) {
+                                                    const float* __restrict__ partial, float* __restrict__ dW, int t_rows) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= (int64_t)n_out * n_in) return;
     const int i = (int)(e / n_in), j = (int)(e % n_in);
@@ -293,7 +295,9 @@ __global__ __launch_bounds__(256) void wgrad_finish(int nchunks, int n_out, int 
         for (int u = 0; u < 8; ++u) t[u] += p[(c + u) * stride];
     }
     for (; c < nchunks; ++c) t[0] += p[c * stride];
-    dW[e] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    const float sum = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    if (t_rows > 0) dW[i < t_rows ? (int64_t)j * t_rows + i : (int64_t)n_in * t_rows + j] = sum;
+    else dW[e] = sum;
 }
 
 // out = act(x W^T + b) for a narrow output (n_out <= 64): the MLP's last layer.  W (n_out x K, zero
@@ -301,11 +305,19 @@ __global__ __launch_bounds__(256) void wgrad_finish(int nchunks, int n_out, int 
 // Lane l = (i = l & 15, kk = l >> 4) reads a run of consecutive k of x's row i and the same k of W's
 // row 16 a + i from LDS; every MFMA step uses one k of the run on both operands (the order of k inside
 // the sum is free).  Register q of the result is out[row 4 kk + q][16 a + i].
-template <int NT, int ACT>
-__global__ __launch_bounds__(1024) void linear_narrow_fwd_kernel(int64_t m, int K, int n_out, const float* __restrict__ x,
-                                                                int64_t ldx, const float* __restrict__ W,
-                                                                const float* __restrict__ b, float* __restrict__ out,
-                                                                int64_t ldo) {
+//
+// GRAM: the kernel also leaves, per workgroup, the float64 partial Gram matrix of the rows below gram_rows of its
+// output (the orthonormalisation of a training step needs out[:gram_rows]^T out[:gram_rows] next, and the output
+// tile of a wave sits in its registers in exactly the layout v_mfma_f64_16x16x4_f64 takes for both operands: step q
+// multiplies the four rows 4 kk + q).  The host launches this form with at most one tile per wave, so that the k x k
+// accumulators (8 NT^2 registers) never live beside the product loop's; the waves' partial matrices are added in four
+// LDS images (over the weights, which nobody reads any more) in wave order and the workgroup writes their sum to
+// slab[blockIdx.x][n_out][n_out].  Workgroups whose rows all lie at or above gram_rows write nothing.
+template <int NT, int ACT, bool GRAM = false>
+__global__ __launch_bounds__(GRAM && NT == 4 ? 512 : 1024)
+void linear_narrow_fwd_kernel(int64_t m, int K, int n_out, const float* __restrict__ x, int64_t ldx,
+                              const float* __restrict__ W, const float* __restrict__ b, float* __restrict__ out,
+                              int64_t ldo, int64_t gram_rows = 0, double* __restrict__ slab = nullptr) {
     extern __shared__ float Ws[];  // [NT * 16][K + 4]
     const int KS = K + 4;
     const int k4 = K >> 2;
@@ -323,7 +335,14 @@ __global__ __launch_bounds__(1024) void linear_narrow_fwd_kernel(int64_t m, int 
     float bias[NT];
 #pragma unroll
     for (int a = 0; a < NT; ++a) bias[a] = (16 * a + i < n_out) ? b[16 * a + i] : 0.f;
-    for (int64_t tile = (int64_t)blockIdx.x * nw + wave; tile < ntiles; tile += (int64_t)gridDim.x * nw) {
+    typedef double gram_acc_t __attribute__((ext_vector_type(4)));
+    float kept[NT][4];   // GRAM: the wave's output tile as it was stored
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) kept[a][q] = 0.f;
+    // (GRAM: one pass at most, the host sizes the grid for it)
+    for (int64_t tile = (int64_t)blockIdx.x * nw + wave; tile < ntiles; tile += GRAM ? ntiles : (int64_t)gridDim.x * nw) {
         const int64_t r = min(tile * 16 + i, m - 1);
         // 64 consecutive k per group: lane (i, kk) reads x[row i][64 T + 16 kk .. + 15] (64 contiguous
         // bytes, a whole 256-byte line per row and wave instruction) and the same k of W's rows
@@ -390,8 +409,50 @@ __global__ __launch_bounds__(1024) void linear_narrow_fwd_kernel(int64_t m, int 
                     if (ACT == ACT_TANH) v = tanhf(v);
                     if (ACT == ACT_RELU) v = fmaxf(v, 0.f);
                     out[row * ldo + c] = v;
+                    if (GRAM && row < gram_rows) kept[a][q] = v;
                 }
             }
+        }
+    }
+    if constexpr (GRAM) {
+        if ((int64_t)blockIdx.x * nw * 16 >= gram_rows) return;   // (the whole workgroup)
+        gram_acc_t g[NT][NT];
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int c = 0; c < NT; ++c) g[a][c] = gram_acc_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double p[NT];
+#pragma unroll
+            for (int a = 0; a < NT; ++a) p[a] = static_cast<double>(kept[a][q]);
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+#pragma unroll
+                for (int c = 0; c < NT; ++c) g[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(p[a], p[c], g[a][c], 0, 0, 0);
+        }
+        constexpr int KP = NT * 16;
+        double* img = reinterpret_cast<double*>(Ws);   // four images [KP][KP]
+        __syncthreads();                               // every wave is done with the weights
+        for (int round = 0; round * 4 < nw; ++round) {
+            if ((wave >> 2) == round) {
+                double* mine = img + (wave & 3) * KP * KP;
+#pragma unroll
+                for (int a = 0; a < NT; ++a)
+#pragma unroll
+                    for (int c = 0; c < NT; ++c)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int e = (a * 16 + kk + 4 * q) * KP + c * 16 + i;
+                            if (round == 0) mine[e] = g[a][c][q]; else mine[e] += g[a][c][q];
+                        }
+            }
+            __syncthreads();
+        }
+        double* dst = slab + (int64_t)blockIdx.x * n_out * n_out;
+        for (int e = threadIdx.x; e < n_out * n_out; e += blockDim.x) {
+            const int o = (e / n_out) * KP + e % n_out;
+            dst[e] = ((img[o] + img[KP * KP + o]) + img[2 * KP * KP + o]) + img[3 * KP * KP + o];
         }
     }
 }
@@ -622,7 +683,7 @@ int wgrad_launch(int first, int64_t m, int n_out, int n_rows_out, int n_in, cons
     SPARC_CHECK_LAUNCH();
     const int64_t total = (int64_t)n_rows_out * n_in;
     hipLaunchKernelGGL(wgrad_finish, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, nchunks, n_rows_out, nt * 16,
-                       n_in, partial, dW);
+                       n_in, partial, dW, first ? n_out : 0);
     SPARC_CHECK_LAUNCH();
     return SPARC_OK;
 }
@@ -643,27 +704,27 @@ extern "C" size_t sparc_first_layer_bwd_workspace_bytes(int din, int n) {
 }
 
 extern "C" int sparc_first_layer_bwd(int64_t m, int din, int n, const float* x, int64_t ldx, const float* g, int64_t ldg,
-                                     const float* h, int64_t ldh, float* dWt_db, void* ws, size_t ws_bytes,
+                                     const float* h, int64_t ldh, float* dW_db, void* ws, size_t ws_bytes,
                                      sparc_stream_t stream) {
-    if (m < 0 || din <= 0 || din + 1 > SPARC_MAX_K || n <= 0 || n % 64 != 0 || !x || !g || !h || !dWt_db || ldx < din ||
+    if (m < 0 || din <= 0 || din + 1 > SPARC_MAX_K || n <= 0 || n % 64 != 0 || !x || !g || !h || !dW_db || ldx < din ||
         ldg < n || ldh < n || ldg % 4 != 0 || ldh % 4 != 0 || !aligned16(g) || !aligned16(h))
         return SPARC_ERR_ARG;
     if (ws_bytes < sparc_first_layer_bwd_workspace_bytes(din, n) || !ws || (reinterpret_cast<uintptr_t>(ws) & 255)) return SPARC_ERR_WS;
     if (m == 0)
-        return hipMemsetAsync(dWt_db, 0, (size_t)(din + 1) * n * sizeof(float), stream) == hipSuccess ? SPARC_OK : SPARC_ERR_LAUNCH;
-    return wgrad_launch(1, m, din, din + 1, n, x, ldx, g, ldg, h, ldh, nullptr, dWt_db, ws, stream);
+        return hipMemsetAsync(dW_db, 0, (size_t)(din + 1) * n * sizeof(float), stream) == hipSuccess ? SPARC_OK : SPARC_ERR_LAUNCH;
+    return wgrad_launch(1, m, din, din + 1, n, x, ldx, g, ldg, h, ldh, nullptr, dW_db, ws, stream);
 }
 
 extern "C" int sparc_first_layer_bwd_recompute(int64_t m, int din, int n, const float* x, int64_t ldx, const float* g, int64_t ldg,
-                                               const float* W, const float* b, float* dWt_db, void* ws, size_t ws_bytes,
+                                               const float* W, const float* b, float* dW_db, void* ws, size_t ws_bytes,
                                                sparc_stream_t stream) {
-    if (m < 0 || din <= 0 || din > 16 || n <= 0 || n % 64 != 0 || !x || !g || !W || !b || !dWt_db || ldx < din || ldg < n ||
+    if (m < 0 || din <= 0 || din > 16 || n <= 0 || n % 64 != 0 || !x || !g || !W || !b || !dW_db || ldx < din || ldg < n ||
         ldg % 4 != 0 || !aligned16(g))
         return SPARC_ERR_ARG;
     if (ws_bytes < sparc_first_layer_bwd_workspace_bytes(din, n) || !ws || (reinterpret_cast<uintptr_t>(ws) & 255)) return SPARC_ERR_WS;
     if (m == 0)
-        return hipMemsetAsync(dWt_db, 0, (size_t)(din + 1) * n * sizeof(float), stream) == hipSuccess ? SPARC_OK : SPARC_ERR_LAUNCH;
-    return wgrad_launch(2, m, din, din + 1, n, x, ldx, g, ldg, W, 0, b, dWt_db, ws, stream);
+        return hipMemsetAsync(dW_db, 0, (size_t)(din + 1) * n * sizeof(float), stream) == hipSuccess ? SPARC_OK : SPARC_ERR_LAUNCH;
+    return wgrad_launch(2, m, din, din + 1, n, x, ldx, g, ldg, W, 0, b, dW_db, ws, stream);
 }
 
 namespace {
@@ -727,6 +788,80 @@ extern "C" int sparc_linear_narrow_fwd(int64_t m, int K, int n_out, int act, con
 #undef SPARC_FWD
     SPARC_CHECK_LAUNCH();
     return SPARC_OK;
+}
+
+namespace {
+constexpr int FWD_GRAM_MAX_PARTS = 256;   // one workgroup per CU
+
+template <int NT, int ACT>
+int configure_narrow_fwd_gram() {
+    static std::mutex mu;
+    static bool done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SPARC_ERR_LAUNCH;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!done[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_narrow_fwd_kernel<NT, ACT, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+            return SPARC_ERR_LAUNCH;
+        done[dev] = true;
+    }
+    return SPARC_OK;
+}
+}  // namespace
+
+extern "C" size_t sparc_linear_narrow_fwd_gram_workspace_bytes(int n_out) {
+    if (n_out < 1 || n_out > SPARC_MAX_K) return 0;
+    return sparc_align_up((size_t)FWD_GRAM_MAX_PARTS * n_out * n_out * sizeof(double));
+}
+
+extern "C" int sparc_linear_narrow_fwd_gram(int64_t m, int K, int n_out, int act, const float* x, int64_t ldx, const float* W,
+                                            const float* b, float* out, int64_t ldo, int64_t gram_rows, double* G, void* ws,
+                                            size_t ws_bytes, sparc_stream_t stream) {
+    if (m <= 0 || K <= 0 || K % 16 != 0 || n_out <= 0 || n_out > SPARC_MAX_K || (act != ACT_RELU && act != ACT_TANH && act != 2) ||
+        !x || !W || !b || !out || !G || ldx < K || ldx % 4 != 0 || ldo < n_out || !aligned16(x) || !aligned16(W) ||
+        gram_rows < 1 || gram_rows > m)
+        return SPARC_ERR_ARG;
+    if (!ws || ws_bytes < sparc_linear_narrow_fwd_gram_workspace_bytes(n_out) || (reinterpret_cast<uintptr_t>(ws) & 255))
+        return SPARC_ERR_WS;
+    const int nt = (n_out + 15) / 16;
+    const size_t lds_w = (size_t)nt * 16 * (K + 4) * sizeof(float);
+    const size_t lds_g = (size_t)4 * nt * 16 * nt * 16 * sizeof(double);
+    const size_t lds = lds_w > lds_g ? lds_w : lds_g;
+    if (lds > 150 * 1024) return SPARC_ERR_ARG;
+    // every wave takes one tile of 16 rows: the fewest waves per workgroup (8 at most for 64 output columns: their
+    // accumulators need the registers of two waves per SIMD) that cover the rows with one workgroup per CU
+    const int64_t ntiles = (m + 15) / 16;
+    const int max_waves = nt == 4 ? 8 : 16;
+    int waves = 8;
+    while (waves < max_waves && (ntiles + waves - 1) / waves > FWD_GRAM_MAX_PARTS) waves += 4;
+    const int64_t nb = (ntiles + waves - 1) / waves;
+    if (nb > FWD_GRAM_MAX_PARTS) return SPARC_ERR_SIZE;
+    const int nparts = (int)((gram_rows + 16 * waves - 1) / (16 * waves));
+    double* slab = static_cast<double*>(ws);
+    dim3 grid((unsigned)nb), block(64 * waves);
+#define SPARC_FWDG(NT_, A_)                                                                                              \
+    do {                                                                                                                 \
+        if (configure_narrow_fwd_gram<NT_, A_>() != SPARC_OK) return SPARC_ERR_LAUNCH;                                   \
+        hipLaunchKernelGGL((linear_narrow_fwd_kernel<NT_, A_, true>), grid, block, lds, stream, m, K, n_out, x, ldx, W, b, out, \
+                           ldo, gram_rows, slab);                                                                        \
+    } while (0)
+#define SPARC_FWDG_ACT(NT_)                                    \
+    do {                                                       \
+        if (act == ACT_RELU) SPARC_FWDG(NT_, ACT_RELU);        \
+        else if (act == ACT_TANH) SPARC_FWDG(NT_, ACT_TANH);   \
+        else SPARC_FWDG(NT_, 2);                               \
+    } while (0)
+    switch (nt) {
+        case 1: SPARC_FWDG_ACT(1); break;
+        case 2: SPARC_FWDG_ACT(2); break;
+        case 3: SPARC_FWDG_ACT(3); break;
+        default: SPARC_FWDG_ACT(4); break;
+    }
+#undef SPARC_FWDG_ACT
+#undef SPARC_FWDG
+    SPARC_CHECK_LAUNCH();
+    return sparc_gram_reduce(n_out, nparts, slab, G, stream);
 }
 
 extern "C" int sparc_linear_narrow_in_fwd(int64_t m, int K, int N, int act, const float* x, int64_t ldx, const float* W,

@@ -11,18 +11,85 @@ namespace {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-constexpr int GRAM_MAX_BLOCKS = 128;
+typedef float float4_t __attribute__((ext_vector_type(4)));
+
+#ifndef SPARC_GRAM_MAX_BLOCKS
+#define SPARC_GRAM_MAX_BLOCKS 128
+#endif
+constexpr int GRAM_MAX_BLOCKS = SPARC_GRAM_MAX_BLOCKS;
+
+// Z[r0 .. r1) = Q[r0 .. r1) W (or W^T) for one wavefront, 16 rows at a time, in float32 on v_mfma_f32_16x16x4: W (k x k,
+// zero padded to 16 NT) in registers in the B-operand layout (lane (kk = lane >> 4, i = lane & 15) holds
+// W[4 s + kk][16 t + i]), the rows of Q read from global memory in the A-operand layout (lane (kk, i): row i, columns
+// 4 s + kk).  Result register q of a lane: row 4 kk + q, column 16 t + i.
+// The wavefront takes the tiles that begin at r0, r0 + step, ... (step: a multiple of 16).
+template <int NT>
+__device__ __forceinline__ void apply_rows_f32(const int64_t r0, const int64_t r1, const int64_t step, const int k,
+                                               const float* __restrict__ Q, const int64_t ldq, const float* __restrict__ W,
+                                               const int transpose_w, float* __restrict__ Z, const int64_t ldz, const int lane) {
+    constexpr int S = 4 * NT;
+    const int i = lane & 15, kk = lane >> 4;
+    float b[NT][S];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int s_ = 0; s_ < S; ++s_) {
+            const int l = 4 * s_ + kk, c = 16 * t + i;
+            b[t][s_] = (l < k && c < k) ? (transpose_w ? W[c * k + l] : W[l * k + c]) : 0.f;
+        }
+    auto request = [&](float (&a)[S], const int64_t rb) {   // (rows past r1: zero, nothing read)
+        const int64_t row = rb + i;
+#pragma unroll
+        for (int s_ = 0; s_ < S; ++s_) {
+            const int l = 4 * s_ + kk;
+            a[s_] = (row < r1 && l < k) ? Q[row * ldq + l] : 0.f;
+        }
+    };
+    auto tile = [&](const float (&a)[S], const int64_t rb) {
+        float4_t acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s_ = 0; s_ < S; ++s_)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s_], b[t][s_], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t r = rb + 4 * kk + q;
+                const int c = 16 * t + i;
+                if (r < r1 && c < k) Z[r * ldz + c] = acc[t][q];   // (r < rb + 16 always)
+            }
+    };
+    // two register sets in turn: a tile's rows are requested before the products of the tile before
+    float a0[S], a1[S];
+    if (r0 < r1) request(a0, r0);
+    for (int64_t rb = r0; rb < r1; rb += 2 * step) {
+        request(a1, rb + step);
+        tile(a0, rb);
+        if (rb + step >= r1) break;
+        request(a0, rb + 2 * step);
+        tile(a1, rb + step);
+    }
+}
 
 // G_b = P[rows of block b]^T Q[rows of block b], accumulated in float64 by
 // v_mfma_f64_16x16x4_f64.  Lane l feeds A[i = l&15][kk = l>>4] = P[r0+kk][16 ti + i] and
 // B[kk][j = l&15] = Q[r0+kk][16 tj + j]; result register q of lane l is
 // G[16 ti + (l>>4) + 4 q][16 tj + (l&15)].
-template <int NT>
-__global__ __launch_bounds__(256) void gram_partial(int64_t m, int k, const float* __restrict__ P, int64_t ldp,
+// AW > 0: the workgroup has AW more wavefronts, which write Z = Q W (or Q W^T, float32) for the same rows, a tile of 16
+// at a time, while the first four accumulate the Gram matrix: the backward of Y = Yt Wo needs Yt^T gY and gY Wo^T from
+// the same two matrices.  (Four: 16.3 us at 24.5 k rows x 47; eight, in 166 registers, 18.1 us; separate launches 18.9.)
+template <int NT, int AW = 0>
+__global__ __launch_bounds__(256 + 64 * AW) void gram_partial(int64_t m, int k, const float* __restrict__ P, int64_t ldp,
                                                     const float* __restrict__ Q, int64_t ldq,
-                                                    int64_t rows_per_block, double* __restrict__ slab) {
+                                                    int64_t rows_per_block, double* __restrict__ slab,
+                                                    const float* __restrict__ W = nullptr, int transpose_w = 0,
+                                                    float* __restrict__ Z = nullptr, int64_t ldz = 0) {
     constexpr int KP = NT * 16;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
+    const bool applies = AW > 0 && threadIdx.x >= 256;   // (wave-uniform)
     const int li = lane & 15, lk = lane >> 4;
     const int64_t base = blockIdx.x * rows_per_block;
     const int64_t end = min(m, base + rows_per_block);
@@ -73,6 +140,11 @@ __global__ __launch_bounds__(256) void gram_partial(int64_t m, int k, const floa
         }
     };
     int64_t rb = w0;
+    if (applies) {
+        const int aw = (threadIdx.x >> 6) - 4;
+        apply_rows_f32<NT>(base + 16 * aw, end, 16 * AW, k, Q, ldq, W, transpose_w, Z, ldz, lane);
+        rb = w1;
+    }
     if (rb + 16 <= w1) {
         float pf0[4][NT], qf0[4][NT], pf1[4][NT], qf1[4][NT];
         load_group(pf0, qf0, rb);
@@ -110,7 +182,7 @@ __global__ __launch_bounds__(256) void gram_partial(int64_t m, int k, const floa
     // waves add into one LDS image in wave order (fixed summation order)
     __shared__ double sm[KP * KP];
     for (int w = 0; w < 4; ++w) {
-        if (wave == w) {
+        if (wave == w && !applies) {
 #pragma unroll
             for (int a = 0; a < NT; ++a)
 #pragma unroll
@@ -125,7 +197,7 @@ __global__ __launch_bounds__(256) void gram_partial(int64_t m, int k, const floa
         __syncthreads();
     }
     double* out = slab + static_cast<int64_t>(blockIdx.x) * k * k;
-    for (int e = threadIdx.x; e < k * k; e += 256) out[e] = sm[(e / k) * KP + (e % k)];
+    for (int e = threadIdx.x; e < k * k; e += blockDim.x) out[e] = sm[(e / k) * KP + (e % k)];
 }
 
 // G = sum of the block partials, in a fixed order: element e is summed by GRAM_SPLIT threads (thread h takes the
@@ -622,7 +694,6 @@ __global__ __launch_bounds__(OWB_THREADS) void orth_weights_bwd_kernel(int64_t m
 //                respect to the orthonormalisation batch.  For an ill-conditioned batch the entries of H are many
 //                orders of magnitude larger than those of the product (they cancel), so rounding H or the partial
 //                sums to float32 would cost the gradient its leading digits.
-typedef float float4_t __attribute__((ext_vector_type(4)));
 template <int NT, bool F64>
 __global__ __launch_bounds__(256) void orth_apply_mfma(int64_t m, int k, const float* __restrict__ Yt, int64_t ld,
                                                        const void* __restrict__ Wv, int transpose_w,
@@ -705,7 +776,7 @@ extern "C" size_t sparc_gram_workspace_bytes(int64_t m, int k) {
 
 namespace {
 int gram_launch(int64_t m, int k, const float* A, int64_t lda, const float* B, int64_t ldb, double* G, double* slab,
-                hipStream_t stream);
+                hipStream_t stream, const float* W = nullptr, int transpose_w = 0, float* Z = nullptr, int64_t ldz = 0);
 
 // Scratch of sparc_gram_static: the partial Gram matrices of at most GRAM_MAX_BLOCKS blocks.  Every GPU the
 // library runs on holds its own copy of this array at its own address for the life of the process; in host
@@ -743,6 +814,21 @@ extern "C" int sparc_gram(int64_t m, int k, const float* A, int64_t lda, const f
     return gram_launch(m, k, A, lda, B, ldb, G, static_cast<double*>(ws), stream);
 }
 
+extern "C" int sparc_gram_apply(int64_t m, int k, const float* A, int64_t lda, const float* B, int64_t ldb, double* G,
+                                const float* W, int transpose_w, float* Z, int64_t ldz, void* ws, size_t ws_bytes,
+                                sparc_stream_t stream) {
+    if (m <= 0 || k < 1 || k > SPARC_MAX_K || !A || !B || !G || !W || !Z || lda < k || ldb < k || ldz < k) return SPARC_ERR_ARG;
+    if (!ws || ws_bytes < sparc_gram_workspace_bytes(m, k) || (reinterpret_cast<uintptr_t>(ws) & 255)) return SPARC_ERR_WS;
+    return gram_launch(m, k, A, lda, B, ldb, G, static_cast<double*>(ws), stream, W, transpose_w, Z, ldz);
+}
+
+extern "C" int sparc_gram_reduce(int k, int nparts, const double* partials, double* G, sparc_stream_t stream) {
+    if (k < 1 || k > SPARC_MAX_K || nparts < 1 || !partials || !G) return SPARC_ERR_ARG;
+    hipLaunchKernelGGL(gram_reduce, dim3((k * k * GRAM_SPLIT + 255) / 256), dim3(256), 0, stream, k * k, nparts, partials, G);
+    SPARC_CHECK_LAUNCH();
+    return SPARC_OK;
+}
+
 extern "C" int sparc_gram_static(int64_t m, int k, const float* A, int64_t lda, const float* B, int64_t ldb, double* G,
                                  sparc_stream_t stream) {
     if (m <= 0 || !A || !B || !G || lda < k || ldb < k) return SPARC_ERR_ARG;
@@ -754,18 +840,28 @@ extern "C" int sparc_gram_static(int64_t m, int k, const float* A, int64_t lda, 
 
 namespace {
 int gram_launch(int64_t m, int k, const float* A, int64_t lda, const float* B, int64_t ldb, double* G, double* slab,
-                hipStream_t stream) {
+                hipStream_t stream, const float* W, int transpose_w, float* Z, int64_t ldz) {
     const int nb = gram_blocks(m);
     int64_t rpb = (m + nb - 1) / nb;
     rpb = (rpb + 15) / 16 * 16;
     const int nparts = static_cast<int>((m + rpb - 1) / rpb);
     const int nt = (k + 15) / 16;
     const dim3 g(static_cast<unsigned>(nparts)), b(256);
-    switch (nt) {
-        case 1: hipLaunchKernelGGL((gram_partial<1>), g, b, 0, stream, m, k, A, lda, B, ldb, rpb, slab); break;
-        case 2: hipLaunchKernelGGL((gram_partial<2>), g, b, 0, stream, m, k, A, lda, B, ldb, rpb, slab); break;
-        case 3: hipLaunchKernelGGL((gram_partial<3>), g, b, 0, stream, m, k, A, lda, B, ldb, rpb, slab); break;
-        default: hipLaunchKernelGGL((gram_partial<4>), g, b, 0, stream, m, k, A, lda, B, ldb, rpb, slab); break;
+    if (Z) {
+        const dim3 b2(256 + 64 * 4);
+        switch (nt) {
+            case 1: hipLaunchKernelGGL((gram_partial<1, 4>), g, b2, 0, stream, m, k, A, lda, B, ldb, rpb, slab, W, transpose_w, Z, ldz); break;
+            case 2: hipLaunchKernelGGL((gram_partial<2, 4>), g, b2, 0, stream, m, k, A, lda, B, ldb, rpb, slab, W, transpose_w, Z, ldz); break;
+            case 3: hipLaunchKernelGGL((gram_partial<3, 4>), g, b2, 0, stream, m, k, A, lda, B, ldb, rpb, slab, W, transpose_w, Z, ldz); break;
+            default: hipLaunchKernelGGL((gram_partial<4, 4>), g, b2, 0, stream, m, k, A, lda, B, ldb, rpb, slab, W, transpose_w, Z, ldz); break;
+        }
+    } else {
+        switch (nt) {
+            case 1: hipLaunchKernelGGL((gram_partial<1>), g, b, 0, stream, m, k, A, lda, B, ldb, rpb, slab); break;
+            case 2: hipLaunchKernelGGL((gram_partial<2>), g, b, 0, stream, m, k, A, lda, B, ldb, rpb, slab); break;
+            case 3: hipLaunchKernelGGL((gram_partial<3>), g, b, 0, stream, m, k, A, lda, B, ldb, rpb, slab); break;
+            default: hipLaunchKernelGGL((gram_partial<4>), g, b, 0, stream, m, k, A, lda, B, ldb, rpb, slab); break;
+        }
     }
     SPARC_CHECK_LAUNCH();
     hipLaunchKernelGGL(gram_reduce, dim3((k * k * GRAM_SPLIT + 255) / 256), b, 0, stream, k * k, nparts, slab, G);

@@ -34,6 +34,18 @@ def gram(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     return G
 
 
+def gram_apply(A: torch.Tensor, B: torch.Tensor, W: torch.Tensor, transpose: bool, out: torch.Tensor) -> torch.Tensor:
+    """A^T B in float64, and out = B W (or B W^T) in float32, in one launch (the two halves of the backward of Yt Wo)."""
+    m, k = A.shape
+    G = torch.empty(k, k, dtype=torch.float64, device=A.device)
+    nbytes = lib.sparc_gram_workspace_bytes(m, k)
+    ws = Workspace.get(nbytes, A.device)
+    with torch.cuda.device(A.device):
+        check(lib.sparc_gram_apply(m, k, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(G), _ptr(W), 1 if transpose else 0,
+                                   _ptr(out), out.stride(0), _ptr(ws), nbytes, _stream()), "sparc_gram_apply")
+    return G
+
+
 def orth_apply(Yt: torch.Tensor, Wo: torch.Tensor, transpose: bool = False, out: torch.Tensor = None) -> torch.Tensor:
     """Yt Wo (or Yt Wo^T); out: float32 rows of stride out.stride(0) to write into (default: a new [m, k] tensor)."""
     m, k = Yt.shape
@@ -77,13 +89,13 @@ def wgrad_small(g: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
 
 def first_layer_bwd(x: torch.Tensor, g: torch.Tensor, h: torch.Tensor, W: torch.Tensor | None = None,
                     b: torch.Tensor | None = None):
-    """(dW [n, din] as a transposed view, db [n]) of a Linear+ReLU layer whose input needs no gradient,
+    """(dW [n, din], db [n]) of a Linear+ReLU layer whose input needs no gradient,
     in one pass over g and h: the masked gradient is never written out.  With W and b (the layer's own
     parameters, for a layer whose forward ran on linear_narrow_in_fwd: at most 16 inputs) the activations h
     are not read either: the kernel recomputes the pre-activations' signs with the forward's arithmetic."""
     m, din = x.shape
     n = g.shape[1]
-    out = torch.empty(din + 1, n, dtype=torch.float32, device=g.device)
+    out = torch.empty((din + 1) * n, dtype=torch.float32, device=g.device)
     nbytes = lib.sparc_first_layer_bwd_workspace_bytes(din, n)
     ws = Workspace.get(nbytes, g.device)
     with torch.cuda.device(g.device):
@@ -93,21 +105,35 @@ def first_layer_bwd(x: torch.Tensor, g: torch.Tensor, h: torch.Tensor, W: torch.
         else:
             check(lib.sparc_first_layer_bwd(m, din, n, _ptr(x), x.stride(0), _ptr(g), g.stride(0), _ptr(h), h.stride(0), _ptr(out),
                                             _ptr(ws), nbytes, _stream()), "sparc_first_layer_bwd")
-    return out[:din].t(), out[din]
+    return out[:din * n].view(n, din), out[din * n:]
 
 
-def linear_narrow_fwd(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, act: int):
-    """act(x W^T + b) on the MFMA kernel for a narrow output layer, or None when the shape does not fit it."""
+FWD_GRAM_MAX_ROWS = {True: 256 * 8 * 16, False: 256 * 16 * 16}   # one 16-row tile per wave, one workgroup per CU (wide: 8 waves)
+
+
+def linear_narrow_fwd(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, act: int, gram_rows: int = 0):
+    """act(x W^T + b) on the MFMA kernel for a narrow output layer, or None when the shape does not fit it.
+    gram_rows > 0: returns (out, G) with G = out[:gram_rows]^T out[:gram_rows] in float64, from the same launch when the
+    batch is small enough for it (G is None otherwise: the caller then asks for the Gram product itself)."""
     m, K = x.shape
     n_out = W.shape[0]
     if (K % 16 or n_out > 64 or ((n_out + 15) // 16) * 16 * (K + 4) * 4 > 150 * 1024 or not x.is_contiguous()
             or not W.is_contiguous() or x.data_ptr() % 16 or W.data_ptr() % 16 or x.dtype != torch.float32):
         return None
     out = torch.empty(m, n_out, dtype=torch.float32, device=x.device)
+    fused = 0 < gram_rows <= m <= FWD_GRAM_MAX_ROWS[n_out > 48]
     with torch.cuda.device(x.device):
+        if fused:
+            G = torch.empty(n_out, n_out, dtype=torch.float64, device=x.device)
+            nbytes = lib.sparc_linear_narrow_fwd_gram_workspace_bytes(n_out)
+            ws = Workspace.get(nbytes, x.device)
+            check(lib.sparc_linear_narrow_fwd_gram(m, K, n_out, int(act), _ptr(x), x.stride(0), _ptr(W), _ptr(b), _ptr(out), n_out,
+                                                   int(gram_rows), _ptr(G), _ptr(ws), nbytes, _stream()),
+                  "sparc_linear_narrow_fwd_gram")
+            return out, G
         check(lib.sparc_linear_narrow_fwd(m, K, n_out, int(act), _ptr(x), x.stride(0), _ptr(W), _ptr(b), _ptr(out), n_out,
                                           _stream()), "sparc_linear_narrow_fwd")
-    return out
+    return (out, None) if gram_rows > 0 else out
 
 
 def linear_narrow_in_fwd(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, act: int):
@@ -159,6 +185,12 @@ class SpectralMLP(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, hook, *params):
+        return SpectralMLP._forward(ctx, x, hook, params, 0)[0]
+
+    @staticmethod
+    def _forward(ctx, x, hook, params, gram_rows):
+        """(y, G): G = y[:gram_rows]^T y[:gram_rows] (float64) when gram_rows > 0 and the output layer's kernel could
+        take the product along, None otherwise."""
         require_gpu(x.device)
         ctx.hook = hook
         Ws, bs = params[0::2], params[1::2]
@@ -169,12 +201,15 @@ class SpectralMLP(torch.autograd.Function):
             if len(acts) == 1 and h is not None:
                 ctx.first_own = True
             acts.append(h if h is not None else torch._addmm_activation(b, acts[-1], W.t()))
-        y = linear_narrow_fwd(acts[-1], Ws[-1], bs[-1], ACT_TANH)
+        G = None
+        y = linear_narrow_fwd(acts[-1], Ws[-1], bs[-1], ACT_TANH, gram_rows)
+        if y is not None and gram_rows > 0:
+            y, G = y
         if y is None:
             y = torch.addmm(bs[-1], acts[-1], Ws[-1].t()).tanh_()
         ctx.save_for_backward(*acts, y, *Ws, bs[0])
         ctx.n_layers = len(Ws)
-        return y
+        return y, G
 
     @staticmethod
     def backward(ctx, gy):
@@ -221,6 +256,28 @@ class SpectralMLP(torch.autograd.Function):
             elif need_x:
                 gx = gp.mm(Ws[0])
         return (gx, None, *grads)
+
+
+class SpectralMLPGram(torch.autograd.Function):
+    """SpectralMLP for the two batches of a training step in one pass: arguments x, hook, gram_rows, W1, b1, ...; returns
+    (y, G) with G = y[:gram_rows]^T y[:gram_rows] in float64 (not differentiable: the orthonormalisation's backward has
+    its own formula in terms of y), an empty tensor when the output layer's kernel could not take the product along."""
+
+    @staticmethod
+    def forward(ctx, x, hook, gram_rows, *params):
+        y, G = SpectralMLP._forward(ctx, x, hook, params, int(gram_rows))
+        if G is None:
+            G = torch.empty(0, dtype=torch.float64, device=y.device)
+        ctx.mark_non_differentiable(G)
+        ctx.set_materialize_grads(False)   # no zero-filled gradient for G on every backward
+        return y, G
+
+    @staticmethod
+    def backward(ctx, gy, _gG):
+        if gy is None:
+            return (None,) * (3 + 2 * ctx.n_layers)
+        gx, _, *grads = SpectralMLP.backward(ctx, gy)
+        return (gx, None, None, *grads)
 
 
 def _wgrad(gp: torch.Tensor, xin: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
@@ -372,32 +429,64 @@ class OrthWeights(torch.autograd.Function):
     """Yt [m, k] -> orthonormalisation weights [k, k]  (src/SpectralTrainer.py:42-70)."""
 
     last_info = None   # device int of the latest call
-    worst_info = {}    # per device: running maximum over all calls since the last check (a device int)
+    # Per device: the failure codes of the calls since the last check.  Every call writes its code into the next slot of
+    # a ring (no kernel of its own to fold it into a running maximum); slot RING carries the maximum of the laps before.
+    RING = 1024
+    _rings = {}
+    _calls = {}
+
+    @classmethod
+    def _info_slot(cls, dev):
+        key = dev.index or 0
+        ring = cls._rings.get(key)
+        if ring is None:
+            ring = cls._rings[key] = torch.zeros(cls.RING + 1, dtype=torch.int32, device=dev)
+            cls._calls[key] = 0
+        n = cls._calls[key]
+        cls._calls[key] = n + 1
+        if n and n % cls.RING == 0:
+            ring[cls.RING:] = ring.max()
+        return ring[n % cls.RING:n % cls.RING + 1]
+
+    @classmethod
+    def worst(cls, device):
+        """int32 [1] on the device: the largest failure code since the previous check (no host sync); None before the
+        first call on this device."""
+        ring = cls._rings.get(torch.device(device).index or 0)
+        return None if ring is None else ring.max().reshape(1)
+
+    @classmethod
+    def set_worst(cls, device, code: int):
+        ring = cls._rings.get(torch.device(device).index or 0)
+        if ring is not None:
+            ring.zero_()
+            ring[cls.RING] = int(code)
 
     @classmethod
     def check_and_reset(cls, device):
         """Largest failure code since the previous check on this device (one host sync), then cleared.
         Non-zero: some call met a Gram matrix that is not positive definite."""
-        key = torch.device(device).index or 0
-        t = cls.worst_info.get(key)
-        if t is None:
+        ring = cls._rings.get(torch.device(device).index or 0)
+        if ring is None:
             return 0
-        code = int(t)
-        t.zero_()
+        code = int(ring.max())
+        ring.zero_()
         return code
 
     @staticmethod
-    def weights(Y, top_idx, mode):
-        """(Wo float32 [k, k], saved float64 [2 k k + k] = Rc, Rinv, signs) for the contiguous-row batch Y [m, k]."""
+    def weights(Y, top_idx, mode, G=None):
+        """(Wo float32 [k, k], saved float64 [2 k k + k] = Rc, Rinv, signs) for the contiguous-row batch Y [m, k].
+        G: Y^T Y in float64 when the caller has it already."""
         m, k = Y.shape
         if k > 64:
             raise ValueError("spectral dimension k must be <= 64")
         dev = Y.device
-        G = gram(Y, Y)
+        if G is None:
+            G = gram(Y, Y)
         Wo = torch.empty(k, k, dtype=torch.float32, device=dev)
         saved = torch.empty(2 * k * k + k, dtype=torch.float64, device=dev)
         Rc, Rinv, signs = saved[:k * k], saved[k * k:2 * k * k], saved[2 * k * k:]
-        info = torch.empty(1, dtype=torch.int32, device=dev)   # written by every call
+        info = OrthWeights._info_slot(dev)   # written by every call
         tidx = None
         if top_idx is not None:
             tidx = _index_to_device(top_idx, dev)
@@ -407,10 +496,6 @@ class OrthWeights(torch.autograd.Function):
             check(lib.sparc_orth_weights(m, k, _ptr(G), _ptr(Y), Y.stride(0), _ptr(tidx), int(mode), _ptr(Wo), _ptr(Rc),
                                          _ptr(Rinv), _ptr(signs), _ptr(info), _stream()), "sparc_orth_weights")
         OrthWeights.last_info = info  # device int; non-zero = Gram matrix not positive definite (checked lazily)
-        key = dev.index or 0
-        if key not in OrthWeights.worst_info:
-            OrthWeights.worst_info[key] = torch.zeros(1, dtype=torch.int32, device=dev)
-        torch.maximum(OrthWeights.worst_info[key], info, out=OrthWeights.worst_info[key])   # no step goes unnoticed
         return Wo, saved
 
     @staticmethod
@@ -455,25 +540,30 @@ class OrthPair(torch.autograd.Function):
     from the Gram product to the factorisation's backward (no casts)."""
 
     @staticmethod
-    def forward(ctx, Yt, m2, top_idx, mode):
+    def forward(ctx, Yt, m2, top_idx, mode, G=None):
         require_gpu(Yt.device)
         Y = _f32c(Yt)
-        Wo, saved = OrthWeights.weights(Y[:m2], top_idx, mode)
+        if G is not None and (G.shape != (Y.shape[1], Y.shape[1]) or G.dtype != torch.float64):
+            G = None   # (the producer of Yt had no Gram matrix to give)
+        Wo, saved = OrthWeights.weights(Y[:m2], top_idx, mode, G)
         out = orth_apply(Y[m2:], Wo)
         ctx.save_for_backward(Y, Wo, saved)
         ctx.m2, ctx.mode = int(m2), int(mode)
         ctx.mark_non_differentiable(Wo)
+        ctx.set_materialize_grads(False)   # no zero-filled gradient for Wo on every backward
         return out, Wo
 
     @staticmethod
     def backward(ctx, gY, _gWo):
+        if gY is None:
+            return None, None, None, None, None
         Y, Wo, saved = ctx.saved_tensors
         m2 = ctx.m2
         g = _f32c(gY)
         gYt = torch.empty_like(Y)
-        orth_apply(g, Wo, transpose=True, out=gYt[m2:])
-        OrthWeights.weights_backward(Y[:m2], saved, gram(Y[m2:], g), ctx.mode, gYt[:m2])
-        return gYt, None, None, None
+        gW = gram_apply(Y[m2:], g, Wo, True, gYt[m2:])     # Yt^T gY, and gY Wo^T into the gradient batch's rows
+        OrthWeights.weights_backward(Y[:m2], saved, gW, ctx.mode, gYt[:m2])
+        return gYt, None, None, None, None
 
 
 class OrthApply(torch.autograd.Function):
@@ -513,7 +603,22 @@ class LapLoss(torch.autograd.Function):
             ctx.save_for_backward(grad)
         return loss.to(torch.float32)
 
+    _units = {}   # per device: the float32 scalar 1 that unit_gradient hands out
+
+    @classmethod
+    def unit_gradient(cls, loss: torch.Tensor) -> torch.Tensor:
+        """The scalar 1 to start the backward from, `loss.backward(gradient=LapLoss.unit_gradient(loss))`: the same
+        gradients as `loss.backward()` without the kernel that fills a fresh tensor of ones and without the one that
+        multiplies d loss / d Y by it (the backward recognises this very tensor)."""
+        key = (loss.device, loss.dtype)
+        if key not in cls._units:
+            cls._units[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
+        return cls._units[key]
+
     @staticmethod
     def backward(ctx, gl):
         (grad,) = ctx.saved_tensors
+        unit = LapLoss._units.get((gl.device, gl.dtype))
+        if unit is not None and gl.data_ptr() == unit.data_ptr() and gl.dim() == 0:
+            return grad, None, None
         return grad * gl, None, None

@@ -15,6 +15,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from .ops import LapLoss
+
 
 def _staged(t: torch.Tensor, group) -> bool:
     """gloo cannot reduce device tensors reliably: rehearsals of the multi-rank path on a GPU
@@ -212,7 +214,7 @@ class ShardedSpectralTrainer:
         self.optimizer.zero_grad(set_to_none=True)   # autograd hands its gradients over as they are: no accumulation
         Y = net.forward_pair(self.features[pid_2], self.features[pid], top_idx=top_idx)
         loss = self.criterion(self.batches[pid], Y, is_normalized=True)
-        loss.backward()
+        loss.backward(gradient=LapLoss.unit_gradient(loss))
         if self.distributed and self.reducer.finish() == 0:
             all_reduce_mean_gradients(self.params, self.group)   # no layer reported: one bucket, one collective
         self.optimizer.step()

@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from .graph import Workspace
+from .ops import LapLoss
 
 
 class GraphedSteps:
@@ -48,7 +49,7 @@ class GraphedSteps:
         self.optimizer.zero_grad(set_to_none=True)
         Y = self.net.forward_pair(self.features[pid_2], self.features[pid], top_idx=self.top_idx)
         loss = self.criterion(self.batches[pid], Y, is_normalized=True)
-        loss.backward()
+        loss.backward(gradient=LapLoss.unit_gradient(loss))
         self.optimizer.step()
         self.orth.copy_(self.net.orthonorm_weights.detach())
         return loss.detach()

@@ -443,6 +443,71 @@ def test_linear_narrow_fwd_matches_float64(dev, m, K, n_out, act):
     assert linear_narrow_fwd(torch.randn(8, 1024, device=dev), torch.randn(33, 1024, device=dev), torch.randn(33, device=dev), 1) is None
 
 
+@pytest.mark.parametrize("m,K,n_out,m2", [(48980, 512, 47, 24490), (3001, 512, 47, 1500), (3001, 512, 47, 3001), (333, 32, 12, 1),
+                                          (15600, 512, 64, 7801), (2000, 64, 32, 17), (40, 16, 1, 33)])
+def test_linear_narrow_fwd_with_gram_in_its_epilogue(dev, m, K, n_out, m2):
+    """The output layer's forward that also leaves out[:m2]^T out[:m2]: the same `out` bit for bit as the plain call, and
+    the Gram matrix of exactly those float32 values (the same exact products as sparc_gram, summed in another order in
+    float64)."""
+    from sparc_amd.ops import gram, linear_narrow_fwd
+    gen = torch.Generator().manual_seed(m + K + m2)
+    x = torch.randn(m, K, generator=gen).to(dev)
+    W = (torch.randn(n_out, K, generator=gen) / K ** 0.5).to(dev)
+    b = torch.randn(n_out, generator=gen).to(dev)
+    plain = linear_narrow_fwd(x, W, b, 1)
+    out, G = linear_narrow_fwd(x, W, b, 1, gram_rows=m2)
+    assert G is not None and G.dtype == torch.float64 and G.shape == (n_out, n_out)
+    assert torch.equal(out, plain)
+    want = out[:m2].double().t() @ out[:m2].double()
+    assert float((G - want).abs().max()) <= 1e-12 * float(want.abs().max())
+    assert float((G - gram(out[:m2], out[:m2])).abs().max()) <= 1e-12 * float(want.abs().max())
+    assert torch.equal(G, G.t())
+
+
+@pytest.mark.parametrize("m,k", [(24490, 47), (1000, 64), (37, 12), (5, 3), (7801, 32)])
+def test_gram_apply_equals_the_two_separate_calls(dev, m, k):
+    from sparc_amd.ops import gram, gram_apply, orth_apply
+    gen = torch.Generator().manual_seed(m + k)
+    A = torch.randn(m, k, generator=gen).to(dev)
+    B = torch.randn(m, k, generator=gen).to(dev)
+    W = torch.randn(k, k, generator=gen).to(dev)
+    for transpose in (True, False):
+        buf = torch.full((m + 3, k + 5), 7.0, device=dev)      # rows of another stride, guard cells around them
+        out = buf[1:m + 1, :k]
+        G = gram_apply(A, B, W, transpose, out)
+        assert torch.equal(G, gram(A, B))
+        assert torch.equal(out, orth_apply(B, W, transpose=transpose))
+        assert float(buf[0].min()) == 7.0 and float(buf[m + 1:].min()) == 7.0 and float(buf[:, k:].min()) == 7.0
+
+
+def test_failure_codes_survive_a_lap_of_the_ring(dev):
+    from sparc_amd.ops import OrthWeights
+    OrthWeights.check_and_reset(dev)
+    good = torch.randn(200, 8, device=dev)
+    bad = torch.zeros(200, 8, device=dev)
+    OrthWeights.weights(bad, None, 0)
+    for _ in range(OrthWeights.RING + 5):
+        OrthWeights.weights(good, None, 0)
+    assert int(OrthWeights.worst(dev)) != 0
+    assert OrthWeights.check_and_reset(dev) != 0 and OrthWeights.check_and_reset(dev) == 0
+    OrthWeights.weights(good, None, 0)
+    assert OrthWeights.check_and_reset(dev) == 0
+
+
+def test_linear_narrow_fwd_with_gram_leaves_large_batches_to_two_calls(dev):
+    from sparc_amd.ops import linear_narrow_fwd
+    m = 256 * 16 * 16 + 1
+    x = torch.randn(m, 32, device=dev)
+    out, G = linear_narrow_fwd(x, torch.randn(8, 32, device=dev), torch.randn(8, device=dev), 1, gram_rows=100)
+    assert out.shape == (m, 8) and G is None
+    from sparc_amd._lib import lib
+    G = torch.empty(8, 8, dtype=torch.float64, device=dev)
+    ws = torch.empty(lib.sparc_linear_narrow_fwd_gram_workspace_bytes(8), dtype=torch.uint8, device=dev)
+    rc = lib.sparc_linear_narrow_fwd_gram(m, 32, 8, 1, x.data_ptr(), 32, x.data_ptr(), x.data_ptr(), out.data_ptr(), 8, 100,
+                                          G.data_ptr(), ws.data_ptr(), ws.numel(), None)
+    assert rc == -4
+
+
 @pytest.mark.parametrize("m,n_out,N", [(3001, 47, 512), (70, 64, 64), (5, 1, 128), (24491, 33, 256)])
 def test_dgrad_narrow_relu_matches_float64(dev, m, n_out, N):
     from sparc_amd.ops import dgrad_narrow_relu
