@@ -341,6 +341,15 @@ size_t sparc_dgrad_narrow_relu_workspace_bytes(int64_t m, int N);
 int sparc_dgrad_narrow_relu(int64_t m, int n_out, int N, const float* g, int64_t ldg, const float* W,
                             const float* hprev, int64_t ldh, float* dx, int64_t ldx, float* db_prev,
                             void* ws, size_t ws_bytes, sparc_stream_t stream);
+/* The same fusion for a WIDE g (K columns, a multiple of 16; N a multiple of 128; rows of g 16-byte aligned): the input
+ * gradient of a hidden Linear layer with the ReLU derivative and the bias gradient of the layer before it in its
+ * epilogue, a float32 GEMM on the f32 matrix cores whose m x N result leaves the registers once, already masked
+ * (autograd of src/SpectralTrainer.py:28-39 under loss.backward(), :237; as a library GEMM followed by
+ * sparc_act_bwd_bias the product is written, read back together with hprev and written again). */
+size_t sparc_dgrad_wide_relu_workspace_bytes(int64_t m, int N);
+int sparc_dgrad_wide_relu(int64_t m, int K, int N, const float* g, int64_t ldg, const float* W, const float* hprev,
+                          int64_t ldh, float* dx, int64_t ldx, float* db_prev, void* ws, size_t ws_bytes,
+                          sparc_stream_t stream);
 
 /* out = act(x W^T + b) for a narrow INPUT: x [m][K] with K <= 16 (the first layer of the MLP on a handful of node
  * features, src/SpectralTrainer.py:28-39), W [N][K] row-major, b [N], out [m][ldo] with N a multiple of 4 and out

@@ -166,6 +166,24 @@ def dgrad_narrow_relu(g: torch.Tensor, W: torch.Tensor, hprev: torch.Tensor):
     return dx, db
 
 
+def dgrad_wide_relu(g: torch.Tensor, W: torch.Tensor, hprev: torch.Tensor):
+    """((g W) * [hprev > 0], its column sums) for a wide g: the input gradient of a hidden layer fused with the ReLU
+    derivative and bias gradient of the layer before it, or None when the shapes do not fit the kernel."""
+    m, K = g.shape
+    N = W.shape[1]
+    if (K % 16 or N % 128 or m == 0 or not g.is_contiguous() or not W.is_contiguous() or not hprev.is_contiguous()
+            or g.dtype != torch.float32 or W.dtype != torch.float32 or g.data_ptr() % 16 or W.data_ptr() % 16):
+        return None
+    dx = torch.empty(m, N, dtype=torch.float32, device=g.device)
+    db = torch.empty(N, dtype=torch.float32, device=g.device)
+    nbytes = lib.sparc_dgrad_wide_relu_workspace_bytes(m, N)
+    ws = Workspace.get(nbytes, g.device)
+    with torch.cuda.device(g.device):
+        check(lib.sparc_dgrad_wide_relu(m, K, N, _ptr(g), g.stride(0), _ptr(W), _ptr(hprev), hprev.stride(0), _ptr(dx), N,
+                                        _ptr(db), _ptr(ws), nbytes, _stream()), "sparc_dgrad_wide_relu")
+    return dx, db
+
+
 def _layer_done(grads, l, hook):
     """hook(layer, dW, db), the second argument of SpectralMLP, is called as soon as a layer's weight and bias gradient
     exist and returns the pair to hand to autograd (a data-parallel trainer copies them into a bucket and starts its
@@ -182,6 +200,8 @@ class SpectralMLP(torch.autograd.Function):
     derivative and bias gradient); the first layer's backward is one pass that never writes the
     masked gradient.  The wide products stay library GEMMs.  Arguments: x, hook, W1, b1, ..., WL, bL (hook: None, or
     a callable told of every layer's gradients during the backward, see _layer_done)."""
+
+    fuse_wide_dgrad = True   # class-wide switch: a hidden layer's input gradient on sparc_dgrad_wide_relu
 
     @staticmethod
     def forward(ctx, x, hook, *params):
@@ -251,7 +271,11 @@ class SpectralMLP(torch.autograd.Function):
             grads[2 * l] = _wgrad(gp, acts[l], Ws[l])
             grads[2 * l + 1] = db
             _layer_done(grads, l, hook)
-            if l > 0:
+            if l > 1 and SpectralMLP.fuse_wide_dgrad:   # layer l - 1 is a hidden layer behind the first: its ReLU rides along
+                pending = dgrad_wide_relu(gp, Ws[l], acts[l])
+                if pending is None:
+                    pending = gp.mm(Ws[l])
+            elif l > 0:
                 pending = gp.mm(Ws[l])
             elif need_x:
                 gx = gp.mm(Ws[0])

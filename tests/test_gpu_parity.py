@@ -508,6 +508,27 @@ def test_linear_narrow_fwd_with_gram_leaves_large_batches_to_two_calls(dev):
     assert rc == -4
 
 
+@pytest.mark.parametrize("m,K,N", [(3001, 512, 1024), (256, 16, 128), (257, 48, 256), (5, 64, 128), (24491, 512, 1024), (1024, 1024, 1024)])
+def test_dgrad_wide_relu_matches_float64(dev, m, K, N):
+    """The hidden layer's input gradient with the previous ReLU's derivative and bias gradient in its epilogue: against
+    float64, and bit for bit the mask (a zero wherever hprev is not positive)."""
+    from sparc_amd.ops import dgrad_wide_relu
+    gen = torch.Generator().manual_seed(m + K + N)
+    g = torch.randn(m, K, generator=gen).to(dev)
+    W = (torch.randn(K, N, generator=gen) / K ** 0.5).to(dev)
+    hprev = torch.relu(torch.randn(m, N, generator=gen)).to(dev)
+    got = dgrad_wide_relu(g, W, hprev)
+    assert got is not None
+    dx, db = got
+    want = (g.double() @ W.double()) * (hprev > 0)
+    assert rel(dx.cpu().numpy(), want.cpu().numpy()) < 1e-5
+    assert bool((dx[hprev <= 0] == 0).all())
+    assert rel(db.cpu().numpy(), want.sum(0).cpu().numpy()) < 1e-5
+    assert rel(db.cpu().numpy(), dx.double().sum(0).cpu().numpy()) < 1e-6
+    # shapes the kernel does not take are left to the library product
+    assert dgrad_wide_relu(g[:, :K - 1].contiguous(), W[:K - 1].contiguous(), hprev) is None or (K - 1) % 16 == 0
+
+
 @pytest.mark.parametrize("m,n_out,N", [(3001, 47, 512), (70, 64, 64), (5, 1, 128), (24491, 33, 256)])
 def test_dgrad_narrow_relu_matches_float64(dev, m, n_out, N):
     from sparc_amd.ops import dgrad_narrow_relu
