@@ -906,71 +906,69 @@ int64_t dgrad_rows_per_block(int64_t m) {
 // once, masked.  float32 in, float32 sums on v_mfma_f32_32x32x2_f32.
 //
 // Workgroup = 256 x 128 tile of dx, four wavefronts in a 2 x 2 arrangement of 128 x 64 (4 x 2 tiles of 32 x 32: 128
-// accumulator registers).  K is walked in chunks of 16: the chunk's 256 x 16 piece of g sits in LDS with rows of 20
-// floats (so that the 16-byte reads of a 16-lane group fall on distinct banks), the 16 x 128 piece of W as it lies in
-// memory.  Lane l = (i = l & 31, h = l >> 5) reads k = 8 c + 4 h + t of g's row i for c = 0, 1 with one 16-byte read each
-// (t = register of the read) and the same k of W's columns with 4-byte reads: matrix instruction (c, t) contracts the
-// two k of its two lane halves (the order of k inside the sum is free).  The next chunk travels from global memory
-// into registers while the current one is multiplied, and into the other LDS buffer behind the products: one barrier
-// per chunk.  Result register r of a 32 x 32 tile: row 8 (r >> 2) + 4 h + (r & 3), column i.
+// accumulator registers), two workgroups per CU.  K is walked in chunks of 16.  Lane l = (i = l & 31, h = l >> 5) reads
+// k = 8 c + 4 h + t of g's row i for c = 0, 1 with one 16-byte LDS read each (t = register of the read) and the same k
+// of W's columns with 4-byte reads: matrix instruction (c, t) contracts the two k of its two lane halves (the order of
+// k inside the sum is free).  Result register r of a 32 x 32 tile: row 8 (r >> 2) + 4 h + (r & 3), column i.
 // Tiles are dealt so that the eight column tiles of a row tile run on one XCD one after the other: g's rows are read
 // from memory once and served to the other seven from that XCD's L2.
-constexpr int GW_BM = 256, GW_BN = 128, GW_BK = 16, GW_AS = 20;
+//
+// The chunks travel from global memory straight into LDS (global_load_lds, 16 bytes per lane, no register on the
+// way) two chunks ahead of the products: three LDS buffers of 24 KB, one barrier per chunk.  A copy instruction fills
+// 1 KB of LDS in lane order, so g's 64-byte rows cannot be padded; instead the four 16-byte pieces of row r are
+// stored in the order piece ^ ((r >> 2) & 3), which puts the 16-byte reads of every 16-lane group on distinct banks.
+// (With the chunk staged through registers and padded rows the same kernel takes 4 % longer: the wave then waits for
+// its loads behind every chunk's products.)
+constexpr int GW_BM = 256, GW_BN = 128, GW_BK = 16;
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 __global__ __launch_bounds__(256, 2) void dgrad_wide_relu_kernel(int64_t m, int K, int N, const float* __restrict__ g,
-                                                                 int64_t ldg, const float* __restrict__ W,
-                                                                 const float* __restrict__ hprev, int64_t ldh,
-                                                                 float* __restrict__ dx, int64_t ldx,
-                                                                 float* __restrict__ partial) {
-    __shared__ __attribute__((aligned(16))) float As[2][GW_BM * GW_AS];
-    __shared__ __attribute__((aligned(16))) float Bs[2][GW_BK * GW_BN];
+                                                                     int64_t ldg, const float* __restrict__ W,
+                                                                     const float* __restrict__ hprev, int64_t ldh,
+                                                                     float* __restrict__ dx, int64_t ldx,
+                                                                     float* __restrict__ partial) {
+    constexpr int A_FLOATS = GW_BM * GW_BK, B_FLOATS = GW_BK * GW_BN, BUF = A_FLOATS + B_FLOATS;
+    __shared__ __attribute__((aligned(1024))) float lds[3 * BUF];
     const int ntn = N / GW_BN;
     const int64_t tile = xcd_contiguous_block(blockIdx.x, gridDim.x);
     const int64_t m0 = (tile / ntn) * GW_BM;
     const int n0 = (int)(tile % ntn) * GW_BN;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
     const int wr = (wave >> 1) * 128, wc = (wave & 1) * 64;
 
-    // this thread's pieces of a chunk: four of g's (row = p / 4, k = 4 (p % 4)), two of W's (k = p / 32, n = 4 (p % 32))
+    // this lane's source of each of the wave's copy instructions (four for g: 16 rows each; two for W: two k each)
     const float* ga[4];
-    int a_lds[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const int p = tid + 256 * u, row = p >> 2, kq = p & 3;
-        ga[u] = g + min(m0 + row, m - 1) * ldg + 4 * kq;   // (rows past the end repeat the last one; never stored)
-        a_lds[u] = row * GW_AS + 4 * kq;
+        const int row = 16 * (4 * wave + u) + (lane >> 2);
+        const int piece = (lane & 3) ^ ((row >> 2) & 3);
+        ga[u] = g + min(m0 + row, m - 1) * ldg + 4 * piece;
     }
     const float* gb[2];
-    int b_lds[2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int p = tid + 256 * u, kr = p >> 5, nq = p & 31;
-        gb[u] = W + (int64_t)kr * N + n0 + 4 * nq;
-        b_lds[u] = kr * GW_BN + 4 * nq;
-    }
-    // (named registers, not arrays: arrays that lambdas take by reference end up in LDS, and the chunk then waits for its
-    // loads before the first product instead of behind the last)
-    float4 ra0, ra1, ra2, ra3, rb0, rb1;
-#define GW_FETCH(k0_)                                                              \
-    do {                                                                           \
-        ra0 = *reinterpret_cast<const float4*>(ga[0] + (k0_));                     \
-        ra1 = *reinterpret_cast<const float4*>(ga[1] + (k0_));                     \
-        ra2 = *reinterpret_cast<const float4*>(ga[2] + (k0_));                     \
-        ra3 = *reinterpret_cast<const float4*>(ga[3] + (k0_));                     \
-        rb0 = *reinterpret_cast<const float4*>(gb[0] + (int64_t)(k0_) * N);        \
-        rb1 = *reinterpret_cast<const float4*>(gb[1] + (int64_t)(k0_) * N);        \
-    } while (0)
-#define GW_STASH(buf_)                                                             \
-    do {                                                                           \
-        *reinterpret_cast<float4*>(&As[buf_][a_lds[0]]) = ra0;                     \
-        *reinterpret_cast<float4*>(&As[buf_][a_lds[1]]) = ra1;                     \
-        *reinterpret_cast<float4*>(&As[buf_][a_lds[2]]) = ra2;                     \
-        *reinterpret_cast<float4*>(&As[buf_][a_lds[3]]) = ra3;                     \
-        *reinterpret_cast<float4*>(&Bs[buf_][b_lds[0]]) = rb0;                     \
-        *reinterpret_cast<float4*>(&Bs[buf_][b_lds[1]]) = rb1;                     \
-    } while (0)
+    for (int u = 0; u < 2; ++u) gb[u] = W + (int64_t)(2 * (2 * wave + u) + (lane >> 5)) * N + n0 + 4 * (lane & 31);
+    // The copies are written as assembly: the compiler would otherwise make every LDS read wait for ALL copies in
+    // flight (it cannot tell the buffer being read from the one being filled), which is the wait this kernel exists to
+    // avoid.  The waits are placed by hand below: the loop contains no other vector memory operation.
+    const unsigned lds_base = (unsigned)(unsigned long)(__attribute__((address_space(3))) const char*)lds;
+    auto copy_chunk = [&](const int c) {
+        const unsigned dst = lds_base + (unsigned)((c % 3) * BUF * 4);
+        const int k0 = c * GW_BK;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float* src = ga[u] + k0;
+            const unsigned at = dst + (unsigned)((4 * wave + u) * 1024);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(at), "v"(src) : "memory", "m0");
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float* src = gb[u] + (int64_t)k0 * N;
+            const unsigned at = dst + (unsigned)(A_FLOATS * 4 + (2 * wave + u) * 1024);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(at), "v"(src) : "memory", "m0");
+        }
+    };
 
     v16f acc[4][2];
 #pragma unroll
@@ -980,27 +978,24 @@ __global__ __launch_bounds__(256, 2) void dgrad_wide_relu_kernel(int64_t m, int 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[rt][ct][r] = 0.f;
 
-#ifdef GW_ABLATE_LOOP
-    const int nchunks = 1;
-#else
     const int nchunks = K / GW_BK;
-#endif
-    GW_FETCH(0);
-    GW_STASH(0);
-    __syncthreads();
+    const int sw = (i >> 2) & 3;   // the piece order of this lane's rows
+    copy_chunk(0);
+    if (nchunks > 1) copy_chunk(1);
     for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
-#ifndef GW_ABLATE_FETCH
-        if (c + 1 < nchunks) GW_FETCH((c + 1) * GW_BK);
-#endif
-        const float* Ab = &As[buf][(wr + i) * GW_AS + 4 * h];
-        const float* Bb = &Bs[buf][(4 * h) * GW_BN + wc + i];
+        // this wave's copies of chunk c have landed (those of chunk c + 1, six instructions, may still travel) ...
+        if (c + 1 < nchunks) __builtin_amdgcn_s_waitcnt(0x0F76);
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_s_barrier();   // ... and everybody else's; nobody reads the buffer of chunk c - 1 any more
+        if (c + 2 < nchunks) copy_chunk(c + 2);
+        const float* Ab = lds + (c % 3) * BUF + (wr + i) * GW_BK;
+        const float* Bb = lds + (c % 3) * BUF + A_FLOATS + (4 * h) * GW_BN + wc + i;
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
             float4 a[4];
             float b[2][4];
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) a[rt] = *reinterpret_cast<const float4*>(Ab + rt * 32 * GW_AS + 8 * cc);
+            for (int rt = 0; rt < 4; ++rt) a[rt] = *reinterpret_cast<const float4*>(Ab + rt * 32 * GW_BK + 4 * ((2 * cc + h) ^ sw));
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -1015,41 +1010,24 @@ __global__ __launch_bounds__(256, 2) void dgrad_wide_relu_kernel(int64_t m, int 
                         acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[ct][t], acc[rt][ct], 0, 0, 0);
                     }
         }
-#ifndef GW_ABLATE_STASH
-        if (c + 1 < nchunks) GW_STASH(buf ^ 1);
-#endif
-#ifndef GW_ABLATE_BARRIER
-        __syncthreads();
-#endif
     }
 
-    // epilogue: mask, store, column sums; the sixteen values of hprev that a 32 x 32 tile needs are requested together
     float cs[2] = {0.f, 0.f};
-    const bool full = m0 + GW_BM <= m;   // (workgroup-uniform: only the last row tile is cut)
-#ifdef GW_ABLATE_EPILOGUE
-    if (m > 0) {   // timing experiment: one value per lane keeps the products alive
-        float t = 0.f;
-        for (int rt = 0; rt < 4; ++rt) for (int ct = 0; ct < 2; ++ct) for (int r = 0; r < 16; ++r) t += acc[rt][ct][r];
-        if (t == 123.456f) dx[0] = t;
-        return;
-    }
-#endif
-    // the eight 32 x 32 tiles in turn, the values of hprev for GW_AHEAD of them in flight (the operand registers of the
-    // product loop are free now)
-    constexpr int GW_AHEAD = 3;
-    float hv[GW_AHEAD][16];
-    auto request = [&](const int q) {   // tile q = 2 rt + ct
+    const bool full = m0 + GW_BM <= m;
+    constexpr int AHEAD = 3;
+    float hv[AHEAD][16];
+    auto request = [&](const int q) {
         const int rt = q >> 1, ct = q & 1;
         const int col = n0 + wc + 32 * ct + i;
         const int64_t row0 = m0 + wr + 32 * rt + 4 * h;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int64_t row = row0 + 8 * (r >> 2) + (r & 3);
-            hv[q % GW_AHEAD][r] = hprev[(full ? row : min(row, m - 1)) * ldh + col];
+            hv[q % AHEAD][r] = hprev[(full ? row : min(row, m - 1)) * ldh + col];
         }
     };
 #pragma unroll
-    for (int q = 0; q < GW_AHEAD; ++q) request(q);
+    for (int q = 0; q < AHEAD; ++q) request(q);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int rt = q >> 1, ct = q & 1;
@@ -1058,16 +1036,16 @@ __global__ __launch_bounds__(256, 2) void dgrad_wide_relu_kernel(int64_t m, int 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int64_t row = row0 + 8 * (r >> 2) + (r & 3);
-            const float v = hv[q % GW_AHEAD][r] > 0.f ? acc[rt][ct][r] : 0.f;
+            const float v = hv[q % AHEAD][r] > 0.f ? acc[rt][ct][r] : 0.f;
             if (full || row < m) {
                 dx[row * ldx + col] = v;
                 cs[ct] += v;
             }
         }
-        if (q + GW_AHEAD < 8) request(q + GW_AHEAD);
+        if (q + AHEAD < 8) request(q + AHEAD);
     }
-    // the column sums of the tile: the two lane halves, then the two wavefronts that share the columns (fixed order)
-    float* red = &As[0][0];   // [2][128]; (the last barrier of the loop is behind every read of the tiles)
+    __syncthreads();   // (the last chunk's buffer may be buffer 0: every wave is done with it)
+    float* red = lds;
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
         cs[ct] += __shfl_xor(cs[ct], 32);
@@ -1076,8 +1054,6 @@ __global__ __launch_bounds__(256, 2) void dgrad_wide_relu_kernel(int64_t m, int 
     __syncthreads();
     if (tid < GW_BN) partial[(tile / ntn) * N + n0 + tid] = red[tid] + red[GW_BN + tid];
 }
-#undef GW_FETCH
-#undef GW_STASH
 
 extern "C" size_t sparc_dgrad_narrow_relu_workspace_bytes(int64_t m, int N) {
     if (m < 0 || N <= 0) return 0;
