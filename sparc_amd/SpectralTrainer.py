@@ -270,7 +270,7 @@ class SpectralTrainer:
             for p in params:                      # every replica starts from rank 0's weights
                 broadcast(p.data, 0)
             reducer = LayerwiseReducer(params)
-            self.spectral_net.grad_ready_hook = reducer.on_layer
+            self.spectral_net.grad_ready_hook = reducer   # (called as hook(layer, dW, db); its destination() lets the backward write into the buckets)
         min_val_loss = 1000000000
         batches = len(feats)
         batches_val = len(vfeats) if n_val_total is None else n_val_total

@@ -61,11 +61,20 @@ ACT_TANH = 1
 ACT_NONE = 2  # a Linear layer without activation (autoencoder bottleneck / output)
 
 
-def act_bwd_bias(g: torch.Tensor, h: torch.Tensor, act: int):
-    """(g * act'(h), column sums of it): the gradient entering a Linear layer and its bias gradient."""
+def _usable(out, shape):
+    """out if it is a float32 contiguous tensor of that shape to write a result into, else None."""
+    ok = out is not None and tuple(out.shape) == tuple(shape) and out.dtype == torch.float32 and out.is_contiguous()
+    return out if ok else None
+
+
+def act_bwd_bias(g: torch.Tensor, h: torch.Tensor, act: int, db_out: torch.Tensor = None):
+    """(g * act'(h), column sums of it): the gradient entering a Linear layer and its bias gradient (written into
+    db_out when one is given)."""
     m, n = h.shape
     gout = torch.empty(m, n, dtype=torch.float32, device=h.device)
-    db = torch.empty(n, dtype=torch.float32, device=h.device)
+    db = _usable(db_out, (n,))
+    if db is None:
+        db = torch.empty(n, dtype=torch.float32, device=h.device)
     nbytes = lib.sparc_act_bwd_bias_workspace_bytes(m, n)
     ws = Workspace.get(nbytes, h.device)
     with torch.cuda.device(h.device):
@@ -74,11 +83,13 @@ def act_bwd_bias(g: torch.Tensor, h: torch.Tensor, act: int):
     return gout, db
 
 
-def wgrad_small(g: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
-    """g^T h for a narrow g [m, n_out <= 64] and h [m, n_in], n_in a multiple of 64."""
+def wgrad_small(g: torch.Tensor, h: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """g^T h for a narrow g [m, n_out <= 64] and h [m, n_in], n_in a multiple of 64 (written into out when one is given)."""
     m, n_out = g.shape
     n_in = h.shape[1]
-    dW = torch.empty(n_out, n_in, dtype=torch.float32, device=h.device)
+    dW = _usable(out, (n_out, n_in))
+    if dW is None:
+        dW = torch.empty(n_out, n_in, dtype=torch.float32, device=h.device)
     nbytes = lib.sparc_wgrad_small_workspace_bytes(n_out, n_in)
     ws = Workspace.get(nbytes, h.device)
     with torch.cuda.device(h.device):
@@ -88,14 +99,16 @@ def wgrad_small(g: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
 
 
 def first_layer_bwd(x: torch.Tensor, g: torch.Tensor, h: torch.Tensor, W: torch.Tensor | None = None,
-                    b: torch.Tensor | None = None):
+                    b: torch.Tensor | None = None, out: torch.Tensor | None = None):
     """(dW [n, din], db [n]) of a Linear+ReLU layer whose input needs no gradient,
     in one pass over g and h: the masked gradient is never written out.  With W and b (the layer's own
     parameters, for a layer whose forward ran on linear_narrow_in_fwd: at most 16 inputs) the activations h
     are not read either: the kernel recomputes the pre-activations' signs with the forward's arithmetic."""
     m, din = x.shape
     n = g.shape[1]
-    out = torch.empty((din + 1) * n, dtype=torch.float32, device=g.device)
+    out = _usable(out, ((din + 1) * n,))     # (the weight gradient followed by the bias gradient: a reducer's bucket)
+    if out is None:
+        out = torch.empty((din + 1) * n, dtype=torch.float32, device=g.device)
     nbytes = lib.sparc_first_layer_bwd_workspace_bytes(din, n)
     ws = Workspace.get(nbytes, g.device)
     with torch.cuda.device(g.device):
@@ -151,13 +164,15 @@ def linear_narrow_in_fwd(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, act:
     return out
 
 
-def dgrad_narrow_relu(g: torch.Tensor, W: torch.Tensor, hprev: torch.Tensor):
+def dgrad_narrow_relu(g: torch.Tensor, W: torch.Tensor, hprev: torch.Tensor, db_out: torch.Tensor = None):
     """((g W) * [hprev > 0], its column sums): input gradient of a narrow layer fused with the ReLU
-    derivative and bias gradient of the layer before it."""
+    derivative and bias gradient of the layer before it (the sums written into db_out when one is given)."""
     m, n_out = g.shape
     N = W.shape[1]
     dx = torch.empty(m, N, dtype=torch.float32, device=g.device)
-    db = torch.empty(N, dtype=torch.float32, device=g.device)
+    db = _usable(db_out, (N,))
+    if db is None:
+        db = torch.empty(N, dtype=torch.float32, device=g.device)
     nbytes = lib.sparc_dgrad_narrow_relu_workspace_bytes(m, N)
     ws = Workspace.get(nbytes, g.device)
     with torch.cuda.device(g.device):
@@ -166,7 +181,7 @@ def dgrad_narrow_relu(g: torch.Tensor, W: torch.Tensor, hprev: torch.Tensor):
     return dx, db
 
 
-def dgrad_wide_relu(g: torch.Tensor, W: torch.Tensor, hprev: torch.Tensor):
+def dgrad_wide_relu(g: torch.Tensor, W: torch.Tensor, hprev: torch.Tensor, db_out: torch.Tensor = None):
     """((g W) * [hprev > 0], its column sums) for a wide g: the input gradient of a hidden layer fused with the ReLU
     derivative and bias gradient of the layer before it, or None when the shapes do not fit the kernel."""
     m, K = g.shape
@@ -175,13 +190,25 @@ def dgrad_wide_relu(g: torch.Tensor, W: torch.Tensor, hprev: torch.Tensor):
             or g.dtype != torch.float32 or W.dtype != torch.float32 or g.data_ptr() % 16 or W.data_ptr() % 16):
         return None
     dx = torch.empty(m, N, dtype=torch.float32, device=g.device)
-    db = torch.empty(N, dtype=torch.float32, device=g.device)
+    db = _usable(db_out, (N,))
+    if db is None:
+        db = torch.empty(N, dtype=torch.float32, device=g.device)
     nbytes = lib.sparc_dgrad_wide_relu_workspace_bytes(m, N)
     ws = Workspace.get(nbytes, g.device)
     with torch.cuda.device(g.device):
         check(lib.sparc_dgrad_wide_relu(m, K, N, _ptr(g), g.stride(0), _ptr(W), _ptr(hprev), hprev.stride(0), _ptr(dx), N,
                                         _ptr(db), _ptr(ws), nbytes, _stream()), "sparc_dgrad_wide_relu")
     return dx, db
+
+
+def _destination(hook, l, W, cache):
+    """(dW_out, db_out, both) where layer l's gradients should be written so that the hook need not copy them: a hook
+    object with a destination(layer, w_shape, b_shape, like) method (a data-parallel reducer's bucket) names them;
+    `both` is the [weight | bias] buffer as one flat tensor.  (None, None, None) otherwise."""
+    if l not in cache:
+        f = getattr(hook, "destination", None)
+        cache[l] = f(l, tuple(W.shape), (W.shape[0],), W) if f is not None else (None, None, None)
+    return cache[l]
 
 
 def _layer_done(grads, l, hook):
@@ -240,8 +267,10 @@ class SpectralMLP(torch.autograd.Function):
         grads = [None] * (2 * L)
         need_x = ctx.needs_input_grad[0]
         # output layer: tanh derivative + bias gradient, weight gradient, input gradient (+ previous ReLU)
-        gp, db = act_bwd_bias(_f32c(gy), y, ACT_TANH)
-        grads[2 * (L - 1)] = _wgrad(gp, acts[L - 1], Ws[L - 1])
+        dest = {}
+        dW_to, db_to, _ = _destination(hook, L - 1, Ws[L - 1], dest)
+        gp, db = act_bwd_bias(_f32c(gy), y, ACT_TANH, db_to)
+        grads[2 * (L - 1)] = _wgrad(gp, acts[L - 1], Ws[L - 1], dW_to)
         grads[2 * (L - 1) + 1] = db
         _layer_done(grads, L - 1, hook)
         gx = None
@@ -252,7 +281,7 @@ class SpectralMLP(torch.autograd.Function):
         # (with its bias gradient) when the fused kernel applies, raw otherwise
         W, h = Ws[L - 1], acts[L - 1]
         if W.shape[0] <= 64 and W.shape[1] % 64 == 0 and W.is_contiguous() and W.data_ptr() % 16 == 0:
-            pending = dgrad_narrow_relu(gp, W, h)
+            pending = dgrad_narrow_relu(gp, W, h, _destination(hook, L - 2, Ws[L - 2], dest)[1])
         else:
             pending = gp.mm(W)
         for l in range(L - 2, -1, -1):   # hidden layers, last to first; acts[l] is layer l's input, acts[l + 1] its output
@@ -263,16 +292,17 @@ class SpectralMLP(torch.autograd.Function):
                 if (l == 0 and not need_x and xin.shape[1] < 64 and hout.shape[1] % 64 == 0 and xin.stride(1) == 1
                         and xin.dtype == torch.float32 and pending.data_ptr() % 16 == 0):
                     own = ctx.first_own and Ws[0].is_contiguous() and xin.shape[1] <= 16
-                    dWt, db = first_layer_bwd(xin, pending, hout, Ws[0] if own else None, b_first if own else None)
+                    dWt, db = first_layer_bwd(xin, pending, hout, Ws[0] if own else None, b_first if own else None,
+                                              _destination(hook, 0, Ws[0], dest)[2])
                     grads[0], grads[1] = dWt, db
                     _layer_done(grads, 0, hook)
                     return (None, None, *grads)
-                gp, db = act_bwd_bias(pending, hout, ACT_RELU)
-            grads[2 * l] = _wgrad(gp, acts[l], Ws[l])
+                gp, db = act_bwd_bias(pending, hout, ACT_RELU, _destination(hook, l, Ws[l], dest)[1])
+            grads[2 * l] = _wgrad(gp, acts[l], Ws[l], _destination(hook, l, Ws[l], dest)[0])
             grads[2 * l + 1] = db
             _layer_done(grads, l, hook)
             if l > 1 and SpectralMLP.fuse_wide_dgrad:   # layer l - 1 is a hidden layer behind the first: its ReLU rides along
-                pending = dgrad_wide_relu(gp, Ws[l], acts[l])
+                pending = dgrad_wide_relu(gp, Ws[l], acts[l], _destination(hook, l - 1, Ws[l - 1], dest)[1])
                 if pending is None:
                     pending = gp.mm(Ws[l])
             elif l > 0:
@@ -304,20 +334,21 @@ class SpectralMLPGram(torch.autograd.Function):
         return (gx, None, None, *grads)
 
 
-def _wgrad(gp: torch.Tensor, xin: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
-    """gp^T xin, on the MFMA kernel when one side is narrow."""
+def _wgrad(gp: torch.Tensor, xin: torch.Tensor, W: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """gp^T xin, on the MFMA kernel when one side is narrow (written into out, a contiguous tensor of W's shape, where
+    the kernel produces that layout)."""
     n_out, n_in = W.shape
     if n_out <= 64 and n_in % 64 == 0 and xin.is_contiguous() and xin.data_ptr() % 16 == 0:
-        return wgrad_small(gp, xin)
+        return wgrad_small(gp, xin, out)
     if n_in <= 64 and n_out % 64 == 0 and gp.data_ptr() % 16 == 0:
         return wgrad_small(xin, gp).t()
-    return wgrad_wide(gp, xin)
+    return wgrad_wide(gp, xin, out)
 
 
 WGRAD_SPLIT_ROWS = 16384   # batches at least this long have their weight gradients summed in four parts
 
 
-def wgrad_wide(gp: torch.Tensor, xin: torch.Tensor) -> torch.Tensor:
+def wgrad_wide(gp: torch.Tensor, xin: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
     """gp^T xin, the weight gradient of a wide layer: a library GEMM.  A result of fewer than 256 tiles of 64 x 64
     (1024 -> 512: 128) leaves half of the CUs idle, because the library does not split the long sum over the rows:
     such a product runs as ONE batched GEMM over four parts of the rows whose partial results are added (489 -> 358 us
@@ -325,12 +356,13 @@ def wgrad_wide(gp: torch.Tensor, xin: torch.Tensor) -> torch.Tensor:
     m, n_out = gp.shape
     n_in = xin.shape[1]
     tiles = ((n_out + 63) // 64) * ((n_in + 63) // 64)
+    out = _usable(out, (n_out, n_in))
     if tiles >= 256 or m < WGRAD_SPLIT_ROWS or not (gp.is_contiguous() and xin.is_contiguous()):
-        return gp.t().mm(xin)
+        return torch.mm(gp.t(), xin, out=out) if out is not None else gp.t().mm(xin)
     parts = 4
     rows = m // parts * parts
-    out = torch.bmm(gp[:rows].view(parts, rows // parts, n_out).transpose(1, 2),
-                    xin[:rows].view(parts, rows // parts, n_in)).sum(0)
+    four = torch.bmm(gp[:rows].view(parts, rows // parts, n_out).transpose(1, 2), xin[:rows].view(parts, rows // parts, n_in))
+    out = torch.sum(four, 0, out=out) if out is not None else four.sum(0)
     if rows < m:
         out.addmm_(gp[rows:].t(), xin[rows:])
     return out

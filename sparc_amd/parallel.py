@@ -97,6 +97,18 @@ class LayerwiseReducer:
             self.buckets[layer] = flat
         return flat
 
+    def destination(self, layer: int, w_shape, b_shape, like: torch.Tensor):
+        """(weight part, bias part, whole bucket) of layer's bucket, for a backward that can write its gradients there
+        itself: on_layer then finds them in place and copies nothing.  The previous step's collective on this bucket
+        has been waited for in finish(), and whatever still reads the old means (the optimiser's update) was enqueued
+        before the kernels that will overwrite them."""
+        n_w, n_b = int(np.prod(w_shape)), int(np.prod(b_shape))
+        flat = self._bucket(layer, n_w + n_b, like)
+        return flat[:n_w].view(w_shape), flat[n_w:].view(b_shape), flat
+
+    def __call__(self, layer: int, dW: torch.Tensor, db: torch.Tensor):
+        return self.on_layer(layer, dW, db)
+
     def on_layer(self, layer: int, dW: torch.Tensor, db: torch.Tensor):
         if self.params is not None and (self.params[2 * layer].grad is not None or self.params[2 * layer + 1].grad is not None):
             raise RuntimeError("LayerwiseReducer: clear the gradients with zero_grad(set_to_none=True) before the backward")
@@ -105,8 +117,11 @@ class LayerwiseReducer:
                                "of a step through the MLP in one pass: SpectralNetModel.forward_pair)")
         n = dW.numel()
         flat = self._bucket(layer, n + db.numel(), dW)
-        flat[:n].view(dW.shape).copy_(dW)              # a transposed view is laid out as the parameter on the way
-        flat[n:].view(db.shape).copy_(db)
+        in_place = lambda t, at: t.is_contiguous() and t.data_ptr() == flat.data_ptr() + 4 * at and t.dtype == flat.dtype
+        if not in_place(dW, 0):
+            flat[:n].view(dW.shape).copy_(dW)          # a transposed view is laid out as the parameter on the way
+        if not in_place(db, n):
+            flat[n:].view(db.shape).copy_(db)
         averaged = False
         if _staged(flat, self.group):          # gloo rehearsal on a GPU: through the host, synchronously
             all_reduce_sum(flat, self.group)
@@ -191,7 +206,7 @@ class ShardedSpectralTrainer:
         bucket after the backward."""
         self.reducer = reducer
         if hasattr(self.net, "grad_ready_hook"):
-            self.net.grad_ready_hook = reducer.on_layer
+            self.net.grad_ready_hook = reducer   # (called as hook(layer, dW, db); its destination() lets the backward write into the buckets)
 
     def add_batch(self, features: torch.Tensor, batch) -> int:
         self.features.append(features.to(self.device, dtype=torch.float32).contiguous())
