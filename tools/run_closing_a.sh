@@ -1,4 +1,4 @@
-# round-3 closing measurements, part A: all GPU tests, the smoke entry point, the default bench plain and under rocprofv3
+# closing measurements, part A: all GPU tests, the smoke entry point, the default bench plain and under rocprofv3, the other workloads, a two-rank rehearsal
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout -k 10 500 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/r3f_full_gpu.log 2>&1 || { tail -n 20 gpurun_out/r3f_full_gpu.log; exit 1; }
 tail -n 1 gpurun_out/r3f_full_gpu.log

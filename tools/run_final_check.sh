@@ -1,4 +1,4 @@
-# the round's closing check on the GPU box: all GPU tests, the smoke entry point, the profiled and the default bench
+# closing check on the GPU box: all GPU tests, the smoke entry point, the profiled and the default bench
 cd $GRAFT_REPO_ROOT
 timeout -k 10 500 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/full_gpu.log 2>&1 || { tail -n 20 gpurun_out/full_gpu.log; exit 1; }
 tail -n 1 gpurun_out/full_gpu.log
