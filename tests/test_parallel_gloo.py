@@ -138,6 +138,20 @@ def _trainer_worker(rank, world, port, out):
         raise AssertionError("a stale .grad must be refused")
     except RuntimeError:
         pass
+    # a backward that writes its gradients into the bucket itself: destination() names the place, on_layer finds them
+    # there, and the collective averages them like copied ones
+    vW, vb = vW.clone(), vb.clone()                  # (views into the bucket that is about to be written again)
+    lin[0].weight.grad = lin[0].bias.grad = None
+    dW_to, db_to, whole = red.destination(0, (3, 4), (3,), gW)
+    assert whole.data_ptr() == first_bucket and dW_to.data_ptr() == first_bucket and db_to.data_ptr() == first_bucket + 4 * 12
+    dW_to.fill_(float(3 * (rank + 1)))
+    db_to.fill_(float(5 * (rank + 1)))
+    got = red(0, dW_to, db_to)                       # (the reducer itself is the hook)
+    assert got[0] is dW_to and got[1] is db_to
+    red.finish()
+    mean = (1 + world) / 2.0
+    assert torch.equal(lin[0].weight.grad, torch.full((3, 4), 3 * mean)) and torch.equal(lin[0].bias.grad, torch.full((3,), 5 * mean))
+    assert lin[0].weight.grad.data_ptr() == first_bucket
     gathered = [torch.zeros_like(w) for _ in range(world)]
     dist.all_gather(gathered, w)
     g0 = [torch.zeros_like(w0) for _ in range(world)]
