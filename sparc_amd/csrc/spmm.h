@@ -42,6 +42,7 @@ struct SpmmArgs {
     double* loss_out;   // the last workgroup to arrive writes loss_scale * (sum of loss_part) here
     double loss_scale;
     int chain_slot;     // which set of arrival counters this call uses
+    int rows_finish;    // row kernel, loss epilogue: the last workgroup to arrive sums the partials (no loss_finish launch)
     ColsumFinish fin;   // EPI_ADD_X0: workgroup c < fin.kp also finishes column c of the column sums
     float* gradY;
     int64_t ldy;

@@ -39,6 +39,7 @@ constexpr int WIN_MAX_RECORDS = SPARC_TILE_MAX_RECORDS;  // rows of one workgrou
 // kernel keeps its finishing launch: with one workgroup per four rows the arrivals cost more than the launch,
 // 6 k workgroups: 39 + 5 us as two launches, 50 us as one.)
 constexpr int CHAIN_SLOTS = 256;
+constexpr int64_t ROWS_FINISH_MAX_BLOCKS = 2048;
 constexpr int CHAIN_SUBS = 64;                 // second-level counters of a large grid, one cache line each
 constexpr int CHAIN_LINE = 32;                 // words per 128-byte line
 constexpr int CHAIN_WORDS = (1 + CHAIN_SUBS) * CHAIN_LINE;   // per slot: the counter and its sub-counters
@@ -544,10 +545,16 @@ __global__ __launch_bounds__(256) void spmm_rows(const SpmmArgs a) {
     }
     if (EPI == EPI_LAP_SINGLE || EPI == EPI_LAP_DUAL) {
         __shared__ double wl[4];
+        __shared__ unsigned int last_flag;
         wloss = wave_sum(wloss);
         if (lane == 0) wl[wave] = wloss;
         __syncthreads();
-        if (threadIdx.x == 0) a.loss_part[blk] = (wl[0] + wl[1]) + (wl[2] + wl[3]);
+        if (a.rows_finish) {   // (grids of a few hundred workgroups: the arrival counter costs less than a launch)
+            if (threadIdx.x == 0) publish(a.loss_part + blk, (wl[0] + wl[1]) + (wl[2] + wl[3]));
+            finish_loss(a, gridDim.x, wl, &last_flag);
+        } else if (threadIdx.x == 0) {
+            a.loss_part[blk] = (wl[0] + wl[1]) + (wl[2] + wl[3]);
+        }
     }
 }
 
@@ -1432,6 +1439,10 @@ int lap_fwd_impl(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* c
         }
     }
     a.Xg = P2; a.out = nullptr; a.X0 = X;
+    // the row kernel's loss: summed by its last workgroup for grids of up to ROWS_FINISH_MAX_BLOCKS workgroups (6 k
+    // workgroups: 39 + 5 us as two launches, 50 us as one), by loss_finish beyond
+    const bool rows_finish = !tiled && sparc_rows_blocks(m) <= ROWS_FINISH_MAX_BLOCKS;
+    a.rows_finish = rows_finish ? 1 : 0;
     {
         Timed last(dual ? EPI_LAP_DUAL : EPI_LAP_SINGLE, stream, 1);
         if (blocks) {
@@ -1443,7 +1454,7 @@ int lap_fwd_impl(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* c
         rcode = dual ? launch_dual<EPI_LAP_DUAL>(kp, a, stream) : launch_single<EPI_LAP_SINGLE>(W, a, stream);
         if (rcode) return rcode;
     }
-    if (!tiled) {   // the windowed kernel's last workgroup has written the loss; the row kernel leaves partials
+    if (!tiled && !rows_finish) {   // the windowed kernel's last workgroup has written the loss; the row kernel leaves partials
         hipLaunchKernelGGL(loss_finish, dim3(1), dim3(256), 0, stream, nparts, loss_part, 1.0 / static_cast<double>(m), loss);
         SPARC_CHECK_LAUNCH();
     }
