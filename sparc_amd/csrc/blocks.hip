@@ -18,6 +18,7 @@
 #include <mutex>
 
 #include "spmm.h"
+#include "chain.h"
 
 namespace {
 
@@ -88,7 +89,12 @@ __device__ __forceinline__ void gather_row(const BlocksArgs& a, const int64_t p0
 
 // FUSED (1024 threads): waves 4..15 gather the stripe's entries outside the blocks into LDS while waves 0..3
 // multiply the block; the epilogue adds the two.  Otherwise 256 threads and the block product alone.
-template <bool ADD, bool FUSED>
+//
+// LAP (with FUSED, a training pass's last product, W = 2 kp): nothing is stored; the finished rows go through the loss /
+// gradient epilogue of the chain instead (the formula of spmm.hip's row_epilogue: rowc = {+-1/rho, S_ii, d + cw,
+// 1/sqrt(d)}, {r, r2, c, c2}).  The lanes of the A^T half leave their corrected products in LDS, the lanes of the A half
+// pick them up, write the gradient and sum the loss; the last workgroup of the grid to arrive adds the partial sums up.
+template <bool ADD, bool FUSED, bool LAP = false>
 __global__ __launch_bounds__(FUSED ? 1024 : 256) void dense_blocks(const BlocksArgs a) {
     extern __shared__ float4 lds4[];
     float* Xs = reinterpret_cast<float*>(lds4);
@@ -99,6 +105,12 @@ __global__ __launch_bounds__(FUSED ? 1024 : 256) void dense_blocks(const BlocksA
     float* Ds = Xs + static_cast<int64_t>(P) * W;
     float* DTs = Ds + P * 32;  // only when the values are not symmetric
     float* Rs = DTs + (a.blkT != a.blk ? P * 32 : 0);  // FUSED: [32][W], the stripe's gathers
+    float* Ex = Rs + 32 * W;                           // LAP: [32][W / 2] corrected products of the A^T half, then [32][8] row constants
+    float* Rc = Ex + 32 * (W / 2);
+    if (LAP && threadIdx.x < 256) {
+        const int i = stripe * 32 + (threadIdx.x >> 3);
+        Rc[threadIdx.x] = i < nc ? a.lap_rowc[static_cast<int64_t>(row0 + i) * SPARC_ROWC + (threadIdx.x & 7)] : 0.f;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, lk = lane >> 5;
 
@@ -203,7 +215,7 @@ __global__ __launch_bounds__(FUSED ? 1024 : 256) void dense_blocks(const BlocksA
         const int half = P >> 1;
         const float* ap = As + (lk * half) * 32 + li;
         const float* bp = Xs + static_cast<int64_t>(lk * half) * W + ct * 32 + li;
-        if (ADD) {  // the own-row operand of the epilogue is requested before the products
+        if (ADD || LAP) {  // the own-row operand of the epilogue is requested before the products
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = min(stripe * 32 + 8 * (r >> 2) + 4 * lk + (r & 3), nc - 1);
@@ -249,6 +261,56 @@ __global__ __launch_bounds__(FUSED ? 1024 : 256) void dense_blocks(const BlocksA
         for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
     }
     if (FUSED) __syncthreads();  // the gathers of the stripe are in LDS
+    if constexpr (LAP) {
+        const int kp = a.lap_kp;
+        const int c = ct * 32 + li;
+        const bool right = c >= kp;
+        const int cl = right ? c - kp : c;
+        float t[16];
+        float ma = 0.f, mb = 0.f, mc = 0.f, cf[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) cf[q] = a.lap_M12[6 * kp + q];
+        if (mine) {
+            const float* Mb = a.lap_M12 + (right ? 3 * kp : 0) + cl;
+            ma = Mb[0]; mb = Mb[kp]; mc = Mb[2 * kp];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rs = 8 * (r >> 2) + 4 * lk + (r & 3);
+                const float* rc = Rc + rs * 8;
+                const float v = acc[r] + Rs[rs * W + c];
+                const float ldiag = (cf[0] + cf[1] * rc[6] + cf[2] * rc[7]) + rc[4] * (cf[3] + cf[4] * rc[6] + cf[5] * rc[7]) +
+                                    rc[5] * (cf[6] + cf[7] * rc[6] + cf[8] * rc[7]);
+                const float u1 = right ? rc[6] : rc[4], u2 = right ? rc[7] : rc[5];
+                t[r] = (rc[0] < 0.f ? 0.f : v - rc[1] * x0[r]) + ((ma + u1 * mb + u2 * mc) - ldiag * x0[r]);
+                if (right) Ex[rs * kp + cl] = t[r];
+            }
+        }
+        __syncthreads();
+        double dot = 0.0;
+        if (mine && !right) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rs = 8 * (r >> 2) + 4 * lk + (r & 3);
+                const int i = stripe * 32 + rs;
+                if (i < nc) {
+                    const float* rc = Rc + rs * 8;
+                    const float wy = fabsf(rc[0]) * t[r];
+                    const float ly = 0.5f * rc[2] * x0[r] - wy;
+                    dot += static_cast<double>(x0[r]) * ly;
+                    if (cl < a.lap_k)
+                        a.lap_gradY[static_cast<int64_t>(row0 + i) * a.lap_ldy + cl] = (rc[2] * x0[r] - wy - Ex[rs * kp + cl]) * (a.lap_inv_m * rc[3]);
+                }
+            }
+        }
+        __shared__ double wl[16];
+        __shared__ unsigned int last_flag;
+        dot = wave_sum(dot);
+        if (lane == 0) wl[wave] = dot;
+        __syncthreads();
+        if (threadIdx.x == 0) publish(a.lap_loss_part + blockIdx.x, ((wl[0] + wl[1]) + wl[2]) + wl[3]);   // (the product waves)
+        sum_loss_if_last(a.lap_counter, a.lap_loss_part, gridDim.x, a.lap_loss_out, a.lap_loss_scale, wl, &last_flag);
+        return;
+    }
     if (mine) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -266,7 +328,7 @@ __global__ __launch_bounds__(FUSED ? 1024 : 256) void dense_blocks(const BlocksA
 }
 
 // Per device and per instantiation: allow the large dynamic LDS allocation.
-template <bool ADD, bool FUSED>
+template <bool ADD, bool FUSED, bool LAP = false>
 int configure() {
     static std::mutex mu;
     static bool done[64] = {};
@@ -274,7 +336,7 @@ int configure() {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SPARC_ERR_LAUNCH;
     std::lock_guard<std::mutex> lock(mu);
     if (!done[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_blocks<ADD, FUSED>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_blocks<ADD, FUSED, LAP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 SPARC_BLOCKS_LDS_BYTES) != hipSuccess)
             return SPARC_ERR_LAUNCH;
         done[dev] = true;
@@ -282,24 +344,25 @@ int configure() {
     return SPARC_OK;
 }
 
-template <bool ADD, bool FUSED>
+template <bool ADD, bool FUSED, bool LAP = false>
 int launch(const BlocksArgs& a0, size_t lds, hipStream_t stream) {
-    if (configure<ADD, FUSED>()) return SPARC_ERR_LAUNCH;
+    if (configure<ADD, FUSED, LAP>()) return SPARC_ERR_LAUNCH;
     BlocksArgs a = a0;
     static const int dbg = [] {  // developer switch for kernel ablation timings, read once
         const char* e = getenv("SPARC_DBG_BLOCKS");
         return e ? atoi(e) : 0;
     }();
     a.dbg = dbg;
-    hipLaunchKernelGGL((dense_blocks<ADD, FUSED>), dim3(static_cast<unsigned>(a.ndesc)), dim3(FUSED ? 1024 : 256), lds, stream, a);
+    hipLaunchKernelGGL((dense_blocks<ADD, FUSED, LAP>), dim3(static_cast<unsigned>(a.ndesc)), dim3(FUSED ? 1024 : 256), lds, stream, a);
     SPARC_CHECK_LAUNCH();
     return SPARC_OK;
 }
 
 }  // namespace
 
-size_t sparc_blocks_lds_bytes(int max_p, int W, bool mirrored, bool fused) {
-    return (static_cast<size_t>(max_p) * W + static_cast<size_t>(mirrored ? 2 : 1) * max_p * 32 + (fused ? 32 * W : 0)) * sizeof(float);
+size_t sparc_blocks_lds_bytes(int max_p, int W, bool mirrored, bool fused, bool lap) {
+    return (static_cast<size_t>(max_p) * W + static_cast<size_t>(mirrored ? 2 : 1) * max_p * 32 + (fused ? 32 * W : 0) +
+            (lap ? 32 * (W / 2) + 32 * 8 : 0)) * sizeof(float);
 }
 
 // fused: the entries outside the blocks (a.r_*) are gathered by the same launch; needs W in {32, 64, 128}
@@ -311,8 +374,15 @@ int sparc_blocks_launch(const BlocksArgs& a, bool add, bool fused, hipStream_t s
     if (a.ndesc <= 0) return SPARC_OK;
     if (a.W % 32 || a.W < 32 || a.W > 128 || a.max_p % 32 || a.max_p < 32) return SPARC_ERR_ARG;
     const bool mirrored = a.blkT != a.blk;
-    const size_t lds = sparc_blocks_lds_bytes(a.max_p, a.W, mirrored, fused);
+    const bool lap = a.lap_rowc != nullptr;
+    const size_t lds = sparc_blocks_lds_bytes(a.max_p, a.W, mirrored, fused, lap);
     if (lds > SPARC_BLOCKS_LDS_BYTES) return SPARC_ERR_ARG;
+    if (lap) {   // the last product of a training pass with its loss / gradient epilogue
+        if (!fused || add || !a.r_rowptr || !a.X0 || a.W != 2 * a.lap_kp || !a.lap_M12 || !a.lap_gradY || !a.lap_loss_part ||
+            !a.lap_loss_out || !a.lap_counter)
+            return SPARC_ERR_ARG;
+        return launch<false, true, true>(a, lds, stream);
+    }
     if (fused) {
         if (!sparc_blocks_can_fuse(a.max_p, a.W, mirrored) || !a.r_rowptr) return SPARC_ERR_ARG;
         return add ? launch<true, true>(a, lds, stream) : launch<false, true>(a, lds, stream);

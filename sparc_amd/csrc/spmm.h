@@ -97,9 +97,20 @@ struct BlocksArgs {
     const float* r_val;
     const float* r_valT;
     int dbg;              // ablation switches for kernel timing experiments (0 in production)
+    // fused launch of a training pass's LAST product: the loss / gradient epilogue on the finished rows (lap_rowc null: none)
+    const float* lap_rowc;      // float[m][SPARC_ROWC]
+    const float* lap_M12;       // [M1; M2; coupling], rows of lap_kp floats
+    int lap_kp, lap_k;          // columns per half (W == 2 lap_kp), columns of Y
+    float lap_inv_m;
+    float* lap_gradY;           // [m][lap_ldy]
+    int64_t lap_ldy;
+    double* lap_loss_part;      // one partial per workgroup
+    double* lap_loss_out;       // the last workgroup to arrive writes lap_loss_scale * (their sum) here
+    double lap_loss_scale;
+    unsigned int* lap_counter;  // this call's arrival counters (device memory; chain.h)
 };
 #define SPARC_BLOCKS_LDS_BYTES (152 * 1024)
-size_t sparc_blocks_lds_bytes(int max_p, int W, bool mirrored, bool fused);
+size_t sparc_blocks_lds_bytes(int max_p, int W, bool mirrored, bool fused, bool lap = false);
 bool sparc_blocks_can_fuse(int max_p, int W, bool mirrored);
 int sparc_blocks_launch(const BlocksArgs& a, bool add, bool fused, hipStream_t stream);
 

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "spmm.h"
+#include "chain.h"
 
 namespace {
 
@@ -36,73 +37,33 @@ constexpr int WIN_MAX_RECORDS = SPARC_TILE_MAX_RECORDS;  // rows of one workgrou
 // by a kernel of their own.  The arrival counters are part of the library image (zero when it is loaded, and put
 // back to zero by the workgroup that finishes); a call takes the next of CHAIN_SLOTS sets, so calls that overlap on
 // one device (other streams) count separately as long as fewer than CHAIN_SLOTS of them are in flight.  (The row
-// kernel keeps its finishing launch: with one workgroup per four rows the arrivals cost more than the launch,
-// 6 k workgroups: 39 + 5 us as two launches, 50 us as one.)
+// kernel does the same up to ROWS_FINISH_MAX_BLOCKS workgroups and keeps its finishing launch beyond: with one workgroup
+// per four rows the arrivals then cost more than the launch, 6 k workgroups: 39 + 5 us as two launches, 50 us as one.)
 constexpr int CHAIN_SLOTS = 256;
 constexpr int64_t ROWS_FINISH_MAX_BLOCKS = 2048;
-constexpr int CHAIN_SUBS = 64;                 // second-level counters of a large grid, one cache line each
-constexpr int CHAIN_LINE = 32;                 // words per 128-byte line
-constexpr int CHAIN_WORDS = (1 + CHAIN_SUBS) * CHAIN_LINE;   // per slot: the counter and its sub-counters
 __device__ unsigned int g_chain_counter[CHAIN_SLOTS * CHAIN_WORDS];
 std::atomic<unsigned int> g_chain_next{0};
 
-// Partial results travel between workgroups through device-scope atomic stores and loads (write-through and
-// read-through the per-XCD L2s), so that no workgroup has to write back or invalidate a whole L2, which is what a
-// device-scope fence costs here (measured: 17 -> 98 us for the last pass with a fence per workgroup).
-__device__ __forceinline__ void publish(double* p, const double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ double collect(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// Called by every thread of every workgroup of the grid after the workgroup's partial results are published.
-// Returns true, in all threads, in the one workgroup that arrives last; there every other workgroup's
-// partial results can be collected.  `flag` is a word of LDS.
-__device__ __forceinline__ bool arrive_last(unsigned int* counter, unsigned int* subs, const unsigned int total, unsigned int* flag) {
-    // this thread's published stores have completed (the fence keeps the compiler from moving them; the wait is
-    // for the write-through stores themselves: vmcnt(0)) ...
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();                                         // ... and so have those of the rest of the workgroup
-    if (threadIdx.x == 0) {
-        // One atomic per workgroup costs about 7 ns when they all hit one word (measured: 6 k workgroups of the row
-        // kernel, +45 us), so a grid of more than 2 CHAIN_SUBS workgroups counts in two levels: workgroup b arrives at
-        // sub-counter b mod CHAIN_SUBS (`subs`: they follow `counter`, a line apart), and the last arrival of every
-        // sub-counter at `counter` itself.
-        bool last;
-        if (subs && total > 2 * CHAIN_SUBS) {
-            const unsigned int j = blockIdx.x % CHAIN_SUBS;
-            const unsigned int mine = (total - j + CHAIN_SUBS - 1) / CHAIN_SUBS;   // workgroups b = j (mod CHAIN_SUBS), b < total
-            unsigned int* sub = subs + j * CHAIN_LINE;
-            last = __hip_atomic_fetch_add(sub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == mine;
-            if (last) {
-                __hip_atomic_store(sub, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == CHAIN_SUBS;
-            }
-        } else {
-            last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == total;
-        }
-        if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // everybody has arrived: ready for the next call
-        *flag = last ? 1u : 0u;
+// The device address of the counters on the current device, for kernels of other source files (nullptr on failure);
+// looked up once per device.
+unsigned int* chain_counters_on_current_device() {
+    static std::mutex mu;
+    static unsigned int* ptr[64] = {};
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ptr[dev]) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_chain_counter)) != hipSuccess || !p) return nullptr;
+        ptr[dev] = static_cast<unsigned int*>(p);
     }
-    __syncthreads();
-    const bool last = *flag != 0u;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    return last;
+    return ptr[dev];
 }
 
 // loss = scale * (sum of the grid's loss partials), summed in a fixed order by the last workgroup
 __device__ __forceinline__ void finish_loss(const SpmmArgs& a, const unsigned int nparts, double* wl, unsigned int* flag) {
-    unsigned int* c = g_chain_counter + static_cast<size_t>(a.chain_slot) * CHAIN_WORDS;
-    if (!arrive_last(c, c + CHAIN_LINE, gridDim.x, flag)) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    double t = 0.0;
-    for (unsigned int i = threadIdx.x; i < nparts; i += blockDim.x) t += collect(a.loss_part + i);
-    t = wave_sum(t);
-    if (lane == 0) wl[wave] = t;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double sum = 0.0;
-        for (int w = 0; w < nwaves; ++w) sum += wl[w];
-        *a.loss_out = sum * a.loss_scale;
-    }
+    sum_loss_if_last(g_chain_counter + static_cast<size_t>(a.chain_slot) * CHAIN_WORDS, a.loss_part, nparts, a.loss_out,
+                     a.loss_scale, wl, flag);
 }
 
 // M1 = C (V^T Yn), M2 = C^T (U^T X2): the 3 x KP matrices of the rank-3 correction, from the block partials of
@@ -1443,6 +1404,21 @@ int lap_fwd_impl(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* c
     // workgroups: 39 + 5 us as two launches, 50 us as one), by loss_finish beyond
     const bool rows_finish = !tiled && sparc_rows_blocks(m) <= ROWS_FINISH_MAX_BLOCKS;
     a.rows_finish = rows_finish ? 1 : 0;
+    // dense blocks, training pass: the block kernel's own launch carries the loss / gradient epilogue when its LDS has
+    // room for the exchange of the two halves
+    const bool blocks_lap = blocks && fuse && dual &&
+                            sparc_blocks_lds_bytes(bl.max_p, bl.W, bl.blkT != bl.blk, true, true) <= SPARC_BLOCKS_LDS_BYTES;
+    if (blocks_lap) {
+        unsigned int* counters = chain_counters_on_current_device();
+        if (!counters) return SPARC_ERR_LAUNCH;
+        Timed last(EPI_LAP_DUAL, stream, 1);
+        bl.Xg = P2; bl.X0 = X; bl.out = nullptr;
+        bl.lap_rowc = rowc; bl.lap_M12 = M12; bl.lap_kp = kp; bl.lap_k = k; bl.lap_inv_m = a.inv_m;
+        bl.lap_gradY = gradY; bl.lap_ldy = ldy; bl.lap_loss_part = loss_part; bl.lap_loss_out = loss;
+        bl.lap_loss_scale = a.loss_scale;
+        bl.lap_counter = counters + static_cast<size_t>(a.chain_slot) * CHAIN_WORDS;
+        return sparc_blocks_launch(bl, false, true, stream);
+    }
     {
         Timed last(dual ? EPI_LAP_DUAL : EPI_LAP_SINGLE, stream, 1);
         if (blocks) {

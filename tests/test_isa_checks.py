@@ -124,9 +124,9 @@ def test_block_kernel_staging_and_registers(tmp_path):
         sync = next(i for i, l in enumerate(ins[last_dma:]) if l.startswith("s_barrier") or l.startswith("ds_add")) + last_dma
         assert any(re.match(r"s_waitcnt vmcnt\(0\)", l) for l in ins[last_dma:sync]), m.group(1)
         assert any("v_mfma_f32_32x32x2" in l for l in ins), m.group(1)
-    assert found == 4
+    assert found == 5     # plain / add, each alone or with the gathers, and the last pass with its loss epilogue
     spills = [int(x) for x in re.findall(r"\.name:\s+\S*dense_blocks\S*\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text)]
-    assert len(spills) == 4 and max(spills) == 0, spills
+    assert len(spills) == 5 and max(spills) == 0, spills
 
 
 def test_wide_dgrad_gemm_loop_waits_only_for_the_chunk_it_reads(tmp_path):
