@@ -120,6 +120,11 @@ __global__ __launch_bounds__(FUSED ? 1024 : 256) void dense_blocks(const BlocksA
     int64_t gp0[GR], gp1[GR];
     int gc[GR];
     float gv[GR], gvt[GR];
+    // the column-sum finish, when it rides: workgroup c < kp owns column c, gather waves 4..9 one of the six sums each
+    // (requested here, summed after the gathers)
+    FinishShare<1> fin;
+    const int fin_wave = wave >= 4 ? wave - 4 : 16;
+    if (FUSED && ADD && !LAP) fin.request(a.fin, fin_wave, lane, 12);
     if (FUSED && wave >= 4) {
 #pragma unroll
         for (int j = 0; j < GR; ++j) {
@@ -261,6 +266,10 @@ __global__ __launch_bounds__(FUSED ? 1024 : 256) void dense_blocks(const BlocksA
         for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
     }
     if (FUSED) __syncthreads();  // the gathers of the stripe are in LDS
+    if (FUSED && ADD && !LAP) {
+        __shared__ double fin_sums[6];
+        fin.finish(a.fin, fin_wave, lane, 12, fin_sums);
+    }
     if constexpr (LAP) {
         const int kp = a.lap_kp;
         const int c = ct * 32 + li;

@@ -2,6 +2,7 @@
 // results passed through device-scope atomic stores and loads.  Shared by the kernels of spmm.hip and blocks.hip.
 #pragma once
 #include "common.h"
+#include "spmm.h"
 
 constexpr int CHAIN_SUBS = 64;                 // second-level counters of a large grid, one cache line each
 constexpr int CHAIN_LINE = 32;                 // words per 128-byte line
@@ -66,3 +67,47 @@ static __device__ __forceinline__ void sum_loss_if_last(unsigned int* counter, c
         *loss_out = sum * loss_scale;
     }
 }
+
+// The finish of the chain's column sums (M1 = C (V^T Yn), M2 = C^T (U^T X2) from the block partials of lap_scale)
+// spread over the workgroups of the first inner pass (the last pass of the chain is the first
+// reader of M12, so it has a whole pass of time): workgroup c < KP owns column c, its wave w the sum over the block
+// partials of row w of the six (V^T Yn: 0-2, U^T X2: 3-5): a lane requests two partials when the kernel starts
+// (at most 128 partials: lap_scale's block limit) and the sums are formed after the workgroup's own work, so the
+// loads cost the pass nothing.  NQ: sums per wave (workgroups of fewer than six waves take two).  One extra
+// workgroup doing all of it was tried first and became the pass's tail (14.4 -> 21.8 us).
+template <int NQ>
+struct FinishShare {
+    float v[NQ][2];
+    __device__ __forceinline__ void request(const ColsumFinish& f, const int wave, const int lane, const int nwaves) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            v[j][0] = v[j][1] = 0.f;
+            const int q = wave + j * nwaves;
+            if (f.colpart && static_cast<int>(blockIdx.x) < f.kp && q < (f.dual ? 6 : 3)) {
+                const float* src = f.colpart + static_cast<int64_t>(q) * f.kp + blockIdx.x;
+                if (lane < f.nparts) v[j][0] = src[static_cast<int64_t>(lane) * 6 * f.kp];
+                if (lane + 64 < f.nparts) v[j][1] = src[static_cast<int64_t>(lane + 64) * 6 * f.kp];
+            }
+        }
+    }
+    // sums: LDS for six doubles; every thread of the workgroup calls this (it holds a barrier)
+    __device__ __forceinline__ void finish(const ColsumFinish& f, const int wave, const int lane, const int nwaves, double* sums) const {
+        if (!f.colpart || static_cast<int>(blockIdx.x) >= f.kp) return;   // uniform over the workgroup
+        const int ns = f.dual ? 6 : 3;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const int q = wave + j * nwaves;
+            const double t = wave_sum(static_cast<double>(v[j][0]) + static_cast<double>(v[j][1]));
+            if (lane == 0 && q < ns) sums[q] = t;
+        }
+        __syncthreads();
+        if (static_cast<int>(threadIdx.x) < ns) {
+            const int q = threadIdx.x;
+            double t = 0.0;
+            for (int b = 0; b < 3; ++b) t += (q < 3 ? f.coupling[q * 3 + b] : f.coupling[b * 3 + (q - 3)]) * sums[q < 3 ? b : 3 + b];
+            f.M12[q * f.kp + blockIdx.x] = static_cast<float>(t);
+        }
+        if (blockIdx.x == 0 && threadIdx.x >= 64 && threadIdx.x < 73) f.M12[6 * f.kp + threadIdx.x - 64] = static_cast<float>(f.coupling[threadIdx.x - 64]);
+        __syncthreads();   // `sums` may be reused by the caller
+    }
+};

@@ -108,6 +108,8 @@ struct BlocksArgs {
     double* lap_loss_out;       // the last workgroup to arrive writes lap_loss_scale * (their sum) here
     double lap_loss_scale;
     unsigned int* lap_counter;  // this call's arrival counters (device memory; chain.h)
+    // fused launch of a training pass's FIRST product: the finish of the chain's column sums rides along (colpart null: none)
+    ColsumFinish fin;
 };
 #define SPARC_BLOCKS_LDS_BYTES (152 * 1024)
 size_t sparc_blocks_lds_bytes(int max_p, int W, bool mirrored, bool fused, bool lap = false);

@@ -106,48 +106,6 @@ __device__ __forceinline__ void colsum_finish_body(const ColsumFinish& f, double
     if (threadIdx.x < 9) f.M12[6 * KP + threadIdx.x] = static_cast<float>(f.coupling[threadIdx.x]);
 }
 
-// The same finish spread over the workgroups of the first inner pass (the last pass of the chain is the first
-// reader of M12, so it has a whole pass of time): workgroup c < KP owns column c, its wave w the sum over the block
-// partials of row w of the six (V^T Yn: 0-2, U^T X2: 3-5): a lane requests two partials when the kernel starts
-// (at most 128 partials: lap_scale's block limit) and the sums are formed after the workgroup's own work, so the
-// loads cost the pass nothing.  NQ: sums per wave (workgroups of fewer than six waves take two).  One extra
-// workgroup doing all of it was tried first and became the pass's tail (14.4 -> 21.8 us).
-template <int NQ>
-struct FinishShare {
-    float v[NQ][2];
-    __device__ __forceinline__ void request(const ColsumFinish& f, const int wave, const int lane, const int nwaves) {
-#pragma unroll
-        for (int j = 0; j < NQ; ++j) {
-            v[j][0] = v[j][1] = 0.f;
-            const int q = wave + j * nwaves;
-            if (f.colpart && static_cast<int>(blockIdx.x) < f.kp && q < (f.dual ? 6 : 3)) {
-                const float* src = f.colpart + static_cast<int64_t>(q) * f.kp + blockIdx.x;
-                if (lane < f.nparts) v[j][0] = src[static_cast<int64_t>(lane) * 6 * f.kp];
-                if (lane + 64 < f.nparts) v[j][1] = src[static_cast<int64_t>(lane + 64) * 6 * f.kp];
-            }
-        }
-    }
-    // sums: LDS for six doubles; every thread of the workgroup calls this (it holds a barrier)
-    __device__ __forceinline__ void finish(const ColsumFinish& f, const int wave, const int lane, const int nwaves, double* sums) const {
-        if (!f.colpart || static_cast<int>(blockIdx.x) >= f.kp) return;   // uniform over the workgroup
-        const int ns = f.dual ? 6 : 3;
-#pragma unroll
-        for (int j = 0; j < NQ; ++j) {
-            const int q = wave + j * nwaves;
-            const double t = wave_sum(static_cast<double>(v[j][0]) + static_cast<double>(v[j][1]));
-            if (lane == 0 && q < ns) sums[q] = t;
-        }
-        __syncthreads();
-        if (static_cast<int>(threadIdx.x) < ns) {
-            const int q = threadIdx.x;
-            double t = 0.0;
-            for (int b = 0; b < 3; ++b) t += (q < 3 ? f.coupling[q * 3 + b] : f.coupling[b * 3 + (q - 3)]) * sums[q < 3 ? b : 3 + b];
-            f.M12[q * f.kp + blockIdx.x] = static_cast<float>(t);
-        }
-        if (blockIdx.x == 0 && threadIdx.x >= 64 && threadIdx.x < 73) f.M12[6 * f.kp + threadIdx.x - 64] = static_cast<float>(f.coupling[threadIdx.x - 64]);
-        __syncthreads();   // `sums` may be reused by the caller
-    }
-};
 
 __global__ __launch_bounds__(1024) void lap_colsum_finish(const ColsumFinish f) {
     __shared__ double S[FINISH_SPLIT * 6 * SPARC_MAX_K];
@@ -1361,12 +1319,13 @@ int lap_fwd_impl(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* c
 #undef SPARC_SCALE
     SPARC_CHECK_LAUNCH();
     ColsumFinish fin = {colpart, coupling, M12, kp, static_cast<int>(p.nscale), dual ? 1 : 0};
-    // rides with the first inner pass when that pass has a workgroup per column with enough waves for the six sums;
-    // the block kernel has no room for a passenger
-    const bool rides = !blocks && p.nscale <= 128 &&
-                       (tiled ? (tiling->ndesc >= kp && tiling->threads >= 6 * 64) : sparc_rows_blocks(m) >= kp);
+    // rides with the first inner pass when that pass has a workgroup per column with enough waves for the six sums
+    // (the fused block kernel: six of its gather waves)
+    const bool rides = p.nscale <= 128 &&
+                       (blocks ? (fuse && bl.ndesc >= kp)
+                               : tiled ? (tiling->ndesc >= kp && tiling->threads >= 6 * 64) : sparc_rows_blocks(m) >= kp);
     if (rides) {
-        a.fin = fin;
+        if (blocks) bl.fin = fin; else a.fin = fin;
     } else {
         hipLaunchKernelGGL(lap_colsum_finish, dim3(1), dim3(min(FINISH_SPLIT, 1024 / (6 * kp)) * 6 * kp), 0, stream, fin);
         SPARC_CHECK_LAUNCH();
@@ -1388,6 +1347,7 @@ int lap_fwd_impl(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* c
             if (rcode) return rcode;
         }
         a.fin = ColsumFinish{};
+        bl.fin = ColsumFinish{};
         a.Xg = P1; a.out = P2;
         if (blocks) {
             bl.Xg = P1; bl.X0 = X; bl.out = P2;
