@@ -376,6 +376,13 @@ def main():
             b0.lap(Y0, True)
         torch.cuda.synchronize()
     check(lib.sparc_profile_end(ctypes.byref(tot_ms), ctypes.byref(launches)), "sparc_profile_end")
+    # what an event pair measures with nothing between its two records (the bracket's own share of avg_kernel_us)
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
+    for e0, e1 in pairs:
+        e0.record()
+        e1.record()
+    torch.cuda.synchronize()
+    empty_pair_us = float(np.median([e0.elapsed_time(e1) for e0, e1 in pairs])) * 1e3
 
     stats = torch.tensor([elapsed, float(nodes)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
@@ -417,6 +424,7 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_recorded_on": traffic_src, "avg_kernel_us": kern_ms * 1e3,
                          "launches_timed": int(launches.value),
+                         "launches_per_event_pair": 2, "event_pair_with_nothing_between_us": empty_pair_us,
                          "algorithmic_bytes_per_launch": per_launch,
                          "algorithmic_bytes_formula": "nnz*(4+4) + 8*(m+1) + 3*m*(2k)*4 (gathered operand, own-row operand, "
                                                       "result; width 2k = [A half | A^T half])",

@@ -71,22 +71,25 @@ static __device__ __forceinline__ void sum_loss_if_last(unsigned int* counter, c
 // The finish of the chain's column sums (M1 = C (V^T Yn), M2 = C^T (U^T X2) from the block partials of lap_scale)
 // spread over the workgroups of the first inner pass (the last pass of the chain is the first
 // reader of M12, so it has a whole pass of time): workgroup c < KP owns column c, its wave w the sum over the block
-// partials of row w of the six (V^T Yn: 0-2, U^T X2: 3-5): a lane requests two partials when the kernel starts
-// (at most 128 partials: lap_scale's block limit) and the sums are formed after the workgroup's own work, so the
+// partials of row w of the six (V^T Yn: 0-2, U^T X2: 3-5): a lane requests its partials when the kernel starts
+// (at most SPARC_SCALE_MAX_BLOCKS: lap_scale's block limit) and the sums are formed after the workgroup's own work, so the
 // loads cost the pass nothing.  NQ: sums per wave (workgroups of fewer than six waves take two).  One extra
 // workgroup doing all of it was tried first and became the pass's tail (14.4 -> 21.8 us).
 template <int NQ>
 struct FinishShare {
-    float v[NQ][2];
+    static constexpr int PL = SPARC_SCALE_MAX_BLOCKS / 64;   // partials per lane
+    float v[NQ][PL];
     __device__ __forceinline__ void request(const ColsumFinish& f, const int wave, const int lane, const int nwaves) {
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
-            v[j][0] = v[j][1] = 0.f;
+#pragma unroll
+            for (int t = 0; t < PL; ++t) v[j][t] = 0.f;
             const int q = wave + j * nwaves;
             if (f.colpart && static_cast<int>(blockIdx.x) < f.kp && q < (f.dual ? 6 : 3)) {
                 const float* src = f.colpart + static_cast<int64_t>(q) * f.kp + blockIdx.x;
-                if (lane < f.nparts) v[j][0] = src[static_cast<int64_t>(lane) * 6 * f.kp];
-                if (lane + 64 < f.nparts) v[j][1] = src[static_cast<int64_t>(lane + 64) * 6 * f.kp];
+#pragma unroll
+                for (int t = 0; t < PL; ++t)
+                    if (lane + 64 * t < f.nparts) v[j][t] = src[static_cast<int64_t>(lane + 64 * t) * 6 * f.kp];
             }
         }
     }
@@ -97,7 +100,10 @@ struct FinishShare {
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
             const int q = wave + j * nwaves;
-            const double t = wave_sum(static_cast<double>(v[j][0]) + static_cast<double>(v[j][1]));
+            double mine = 0.0;
+#pragma unroll
+            for (int t = 0; t < PL; ++t) mine += static_cast<double>(v[j][t]);
+            const double t = wave_sum(mine);
             if (lane == 0 && q < ns) sums[q] = t;
         }
         __syncthreads();

@@ -14,6 +14,10 @@ enum SpmmEpilogue {
 
 // The column-sum finish of the Laplacian chain (spmm.hip: colsum_finish_body), which the first inner pass can
 // carry spread over its workgroups; colpart == null: none.
+// most workgroups of lap_scale = most block partials of the chain's column sums (a multiple of 64)
+#ifndef SPARC_SCALE_MAX_BLOCKS
+#define SPARC_SCALE_MAX_BLOCKS 128
+#endif
 struct ColsumFinish {
     const float* colpart;    // [nparts][6][kp] block partials of lap_scale
     const double* coupling;  // the 3 x 3 coupling

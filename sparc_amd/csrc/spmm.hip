@@ -902,7 +902,10 @@ __global__ __launch_bounds__(256) void lap_scale(int64_t m, int k, int64_t ldy, 
         for (int u = 0; u < 4; ++u) s[q][u] = 0.f;
     if (rg < RG) {
         // the pass is latency bound: the loads of B rows are requested before the first of them is used
-        constexpr int B = 4;
+#ifndef SPARC_SCALE_AHEAD
+#define SPARC_SCALE_AHEAD 4
+#endif
+        constexpr int B = SPARC_SCALE_AHEAD;
         for (int64_t r0 = base + rg; r0 < end; r0 += B * RG) {
             float4 rc0[B], rc1[B];
             float yv[B][4], rf[B];
@@ -1217,7 +1220,7 @@ extern "C" int sparc_spmm_split(int64_t m, int64_t nnz, const int64_t* rowptr, c
 }
 
 namespace {
-constexpr int SCALE_MAX_BLOCKS = 128;
+constexpr int SCALE_MAX_BLOCKS = SPARC_SCALE_MAX_BLOCKS;
 // Columns per half: the windowed kernel takes multiples of 16, the row kernels 16, 32 or 64.
 int padded_k(int k, bool tiled) { return tiled ? (k + 15) / 16 * 16 : (k <= 16 ? 16 : (k <= 32 ? 32 : 64)); }
 
@@ -1321,7 +1324,7 @@ int lap_fwd_impl(int64_t m, int64_t nnz, const int64_t* rowptr, const int32_t* c
     ColsumFinish fin = {colpart, coupling, M12, kp, static_cast<int>(p.nscale), dual ? 1 : 0};
     // rides with the first inner pass when that pass has a workgroup per column with enough waves for the six sums
     // (the fused block kernel: six of its gather waves)
-    const bool rides = p.nscale <= 128 &&
+    const bool rides = p.nscale <= SCALE_MAX_BLOCKS &&
                        (blocks ? (fuse && bl.ndesc >= kp)
                                : tiled ? (tiling->ndesc >= kp && tiling->threads >= 6 * 64) : sparc_rows_blocks(m) >= kp);
     if (rides) {
