@@ -350,6 +350,19 @@ size_t sparc_dgrad_wide_relu_workspace_bytes(int64_t m, int N);
 int sparc_dgrad_wide_relu(int64_t m, int K, int N, const float* g, int64_t ldg, const float* W, const float* hprev,
                           int64_t ldh, float* dx, int64_t ldx, float* db_prev, void* ws, size_t ws_bytes,
                           sparc_stream_t stream);
+/* The same product when the layer before is the network's FIRST layer (din <= 16 inputs xin [m][ldxi] that need no
+ * gradient, weights W0 [N][din], bias b0, forward computed by sparc_linear_narrow_in_fwd): the masked product
+ * dx = (g W) * [x W0^T + b0 > 0] is only ever used for that layer's weight and bias gradient, so it is not stored at all:
+ * dW_db = [dW [N][din] | db [N]] with dW[n][j] = sum over rows of dx[row][n] xin[row][j] and db[n] = sum over rows of
+ * dx[row][n] come out of the product's epilogue as din + 1 column sums per tile (the layout of sparc_first_layer_bwd's
+ * result).  The ReLU derivative is recomputed with the forward's own sequence of fused multiply-adds (the same bits, the
+ * same sign), so the epilogue reads nothing but the tile's rows of xin.  Replaces a library GEMM that writes m x N floats
+ * and the pass of sparc_first_layer_bwd_recompute that reads them back (autograd of src/SpectralTrainer.py:28-39 under
+ * loss.backward(), :237). */
+size_t sparc_dgrad_wide_first_workspace_bytes(int64_t m, int N, int din);
+int sparc_dgrad_wide_first(int64_t m, int K, int N, int din, const float* g, int64_t ldg, const float* W,
+                           const float* xin, int64_t ldxi, const float* W0, const float* b0, float* dW_db, void* ws,
+                           size_t ws_bytes, sparc_stream_t stream);
 
 /* out = act(x W^T + b) for a narrow INPUT: x [m][K] with K <= 16 (the first layer of the MLP on a handful of node
  * features, src/SpectralTrainer.py:28-39), W [N][K] row-major, b [N], out [m][ldo] with N a multiple of 4 and out

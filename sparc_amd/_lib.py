@@ -87,6 +87,8 @@ _SIGS = {
     "sparc_dgrad_narrow_relu": (c_int, [c_int64, c_int, c_int, P, c_int64, P, P, c_int64, P, c_int64, P, P, c_size_t, P]),
     "sparc_dgrad_wide_relu_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "sparc_dgrad_wide_relu": (c_int, [c_int64, c_int, c_int, P, c_int64, P, P, c_int64, P, c_int64, P, P, c_size_t, P]),
+    "sparc_dgrad_wide_first_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "sparc_dgrad_wide_first": (c_int, [c_int64, c_int, c_int, c_int, P, c_int64, P, P, c_int64, P, P, P, P, c_size_t, P]),
     "sparc_adam_step": (c_int, [c_int, P, c_double, c_double, c_double, c_double, c_double, c_int64, P]),
     "sparc_row_rank_values": (c_int, [c_int64, c_int64, P, c_int64, c_int, P, P, P]),
     "sparc_label_scores": (c_int, [c_int64, P, P, P, P, c_int64, P, c_int, P, P, P, P]),

@@ -83,9 +83,11 @@ __global__ __launch_bounds__(256) void act_bwd_bias_kernel(int64_t m, int n, con
     }
 }
 
-// db[c] = sum over the row blocks of partial[b][c]; 64 columns x 16 lanes per workgroup.
+// db[c] = sum over the row blocks of partial[b][c]; 64 columns x 16 lanes per workgroup.  din > 0: the n columns are
+// din + 1 rows of n / (din + 1) sums (row j < din: column j of a weight gradient [n'][din], row din: its bias gradient)
+// and are written as the weight gradient followed by the bias gradient.
 __global__ __launch_bounds__(64 * COLSUM_LANES) void colsum_finish(int nparts, int n, const float* __restrict__ partial,
-                                                                    float* __restrict__ db) {
+                                                                    float* __restrict__ db, int din = 0) {
     __shared__ float red[COLSUM_LANES][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int lane = threadIdx.x >> 6;
@@ -104,7 +106,12 @@ __global__ __launch_bounds__(64 * COLSUM_LANES) void colsum_finish(int nparts, i
         float s = 0.f;
 #pragma unroll
         for (int l = 0; l < COLSUM_LANES; ++l) s += red[l][threadIdx.x & 63];
-        db[c] = s;
+        if (din > 0) {
+            const int nn = n / (din + 1), j = c / nn, o = c % nn;
+            db[j < din ? o * din + j : nn * din + o] = s;
+        } else {
+            db[c] = s;
+        }
     }
 }
 
@@ -629,7 +636,7 @@ extern "C" int sparc_act_bwd_bias(int64_t m, int n, int act, const float* g, int
     }
 #undef SPARC_ACT_LAUNCH
     SPARC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(colsum_finish, dim3((n + 63) / 64), dim3(64 * COLSUM_LANES), 0, stream, p.nparts, n, partial, db);
+    hipLaunchKernelGGL(colsum_finish, dim3((n + 63) / 64), dim3(64 * COLSUM_LANES), 0, stream, p.nparts, n, partial, db, 0);
     SPARC_CHECK_LAUNCH();
     return SPARC_OK;
 }
@@ -919,14 +926,23 @@ int64_t dgrad_rows_per_block(int64_t m) {
 // stored in the order piece ^ ((r >> 2) & 3), which puts the 16-byte reads of every 16-lane group on distinct banks.
 // (With the chunk staged through registers and padded rows the same kernel takes 4 % longer: the wave then waits for
 // its loads behind every chunk's products.)
+//
+// DP > 0 (the layer before is the network's first, on din <= DP inputs xin that need no gradient, weights w0 [N][din] and
+// bias b0, its forward computed by linear_narrow_in_fwd_kernel): neither is hprev read nor dx stored;
+// the weight and bias gradient of that first layer, dW[n][j] = sum over rows of dx[row][n] xin[row][j] and db[n] =
+// sum over rows of dx[row][n], leave the registers as din + 1 column sums per tile instead (a lane owns a column, its
+// registers are rows: the sums run down the registers): partial[row tile][din + 1][N].
 constexpr int GW_BM = 256, GW_BN = 128, GW_BK = 16;
 typedef float v16f __attribute__((ext_vector_type(16)));
 
+template <int DP>
 __global__ __launch_bounds__(256, 2) void dgrad_wide_relu_kernel(int64_t m, int K, int N, const float* __restrict__ g,
                                                                      int64_t ldg, const float* __restrict__ W,
                                                                      const float* __restrict__ hprev, int64_t ldh,
                                                                      float* __restrict__ dx, int64_t ldx,
-                                                                     float* __restrict__ partial) {
+                                                                     float* __restrict__ partial,
+                                                                     const float* __restrict__ xin, int64_t ldxi, int din,
+                                                                     const float* __restrict__ w0, const float* __restrict__ b0) {
     constexpr int A_FLOATS = GW_BM * GW_BK, B_FLOATS = GW_BK * GW_BN, BUF = A_FLOATS + B_FLOATS;
     __shared__ __attribute__((aligned(1024))) float lds[3 * BUF];
     const int ntn = N / GW_BN;
@@ -1014,45 +1030,126 @@ __global__ __launch_bounds__(256, 2) void dgrad_wide_relu_kernel(int64_t m, int 
 
     float cs[2] = {0.f, 0.f};
     const bool full = m0 + GW_BM <= m;
-    constexpr int AHEAD = 3;
-    float hv[AHEAD][16];
-    auto request = [&](const int q) {
-        const int rt = q >> 1, ct = q & 1;
-        const int col = n0 + wc + 32 * ct + i;
-        const int64_t row0 = m0 + wr + 32 * rt + 4 * h;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t row = row0 + 8 * (r >> 2) + (r & 3);
-            hv[q % AHEAD][r] = hprev[(full ? row : min(row, m - 1)) * ldh + col];
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f wsum[DP > 0 ? DP : 1];   // DP: the weighted column sums of this lane's two columns (one per column tile), as pairs
+    if constexpr (DP > 0) {
+        // The ReLU derivative is not read but recomputed: the first layer's forward (linear_narrow_in_fwd_kernel) forms a
+        // pre-activation as b + sum_k x[k] W[c][k] by fused multiply-adds in the order k = 0, 1, ... (zero padded), so
+        // the same sequence gives the same bits and the same sign; the epilogue then touches no memory but the tile's
+        // rows of xin.  These wait in LDS, [256][DP], zero beyond din and beyond the last row.
+        float* xs = lds;
+        __syncthreads();   // every wave is done with the chunk buffers
+        for (int e = tid; e < GW_BM * DP; e += 256) {
+            const int row = e / DP, j = e % DP;
+            xs[e] = (j < din && m0 + row < m) ? xin[(m0 + row) * ldxi + j] : 0.f;
         }
-    };
+        v2f w2[DP], b2;   // the first layer's weights and bias of the lane's two columns
+        {
+            const int64_t c0 = n0 + wc + i, c1 = c0 + 32;
+            b2 = v2f{b0[c0], b0[c1]};
 #pragma unroll
-    for (int q = 0; q < AHEAD; ++q) request(q);
+            for (int k = 0; k < DP; ++k) w2[k] = k < din ? v2f{w0[c0 * din + k], w0[c1 * din + k]} : v2f{0.f, 0.f};
+        }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int rt = q >> 1, ct = q & 1;
-        const int col = n0 + wc + 32 * ct + i;
-        const int64_t row0 = m0 + wr + 32 * rt + 4 * h;
+        for (int j = 0; j < DP; ++j) wsum[j] = v2f{0.f, 0.f};
+        v2f cs2 = {0.f, 0.f};
+        const int rows_left = (int)min((int64_t)GW_BM, m - m0) - wr - 4 * h;   // local rows below this are real
+        __syncthreads();
+        // A row of xin per step (both lane halves read one address each).  Two rows make a basic block of their own
+        // (a condition that is always true, but not to the compiler): in one block the compiler requests all 64 rows
+        // before the first sum, on top of the 128 accumulators, and spills.
+        const float* xq = xs + (wr + 4 * h) * DP;
+        int go = 1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t row = row0 + 8 * (r >> 2) + (r & 3);
-            const float v = hv[q % AHEAD][r] > 0.f ? acc[rt][ct][r] : 0.f;
-            if (full || row < m) {
-                dx[row * ldx + col] = v;
-                cs[ct] += v;
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int rq = 0; rq < 8; ++rq) {
+                asm volatile("" : "+s"(go));
+                if (go) {
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr) {
+                        const int r = 2 * rq + rr;
+                        const int local = 32 * rt + 8 * (r >> 2) + (r & 3);
+                        const float* xr = xq + local * DP;
+                        float xv[DP];
+#pragma unroll
+                        for (int j4 = 0; j4 < DP; j4 += 4) {
+                            const float4 t = *reinterpret_cast<const float4*>(xr + j4);
+                            xv[j4] = t.x; xv[j4 + 1] = t.y; xv[j4 + 2] = t.z; xv[j4 + 3] = t.w;
+                        }
+                        v2f pre = b2;
+#pragma unroll
+                        for (int k = 0; k < DP; ++k) pre = __builtin_elementwise_fma(v2f{xv[k], xv[k]}, w2[k], pre);
+                        const bool real = full || local < rows_left;
+                        const v2f v = {(pre[0] > 0.f && real) ? acc[rt][0][r] : 0.f, (pre[1] > 0.f && real) ? acc[rt][1][r] : 0.f};
+                        cs2 += v;
+#pragma unroll
+                        for (int j = 0; j < DP; ++j) wsum[j] = __builtin_elementwise_fma(v, v2f{xv[j], xv[j]}, wsum[j]);
+                    }
+                }
+            }
+        cs[0] = cs2[0];
+        cs[1] = cs2[1];
+    } else {
+        constexpr int AHEAD = 3;
+        float hv[AHEAD][16];
+        auto request = [&](const int q) {
+            const int rt = q >> 1, ct = q & 1;
+            const int col = n0 + wc + 32 * ct + i;
+            const int64_t row0 = m0 + wr + 32 * rt + 4 * h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = row0 + 8 * (r >> 2) + (r & 3);
+                hv[q % AHEAD][r] = hprev[(full ? row : min(row, m - 1)) * ldh + col];
+            }
+        };
+#pragma unroll
+        for (int q = 0; q < AHEAD; ++q) request(q);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int rt = q >> 1, ct = q & 1;
+            const int col = n0 + wc + 32 * ct + i;
+            const int64_t row0 = m0 + wr + 32 * rt + 4 * h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = row0 + 8 * (r >> 2) + (r & 3);
+                const float v = hv[q % AHEAD][r] > 0.f ? acc[rt][ct][r] : 0.f;
+                if (full || row < m) {
+                    dx[row * ldx + col] = v;
+                    cs[ct] += v;
+                }
+            }
+            if (q + AHEAD < 8) request(q + AHEAD);
+        }
+    }
+    __syncthreads();   // (the last chunk's buffer may be buffer 0: every wave is done with it; DP: everybody has read xs)
+    if constexpr (DP > 0) {
+        float* red = lds;   // [2 row halves][DP + 1][128]
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            cs[ct] += __shfl_xor(cs[ct], 32);
+            if (h == 0) red[((wave >> 1) * (DP + 1) + DP) * GW_BN + wc + 32 * ct + i] = cs[ct];
+#pragma unroll
+            for (int j = 0; j < DP; ++j) {
+                const float t = wsum[j][ct] + __shfl_xor(wsum[j][ct], 32);
+                if (h == 0) red[((wave >> 1) * (DP + 1) + j) * GW_BN + wc + 32 * ct + i] = t;
             }
         }
-        if (q + AHEAD < 8) request(q + AHEAD);
-    }
-    __syncthreads();   // (the last chunk's buffer may be buffer 0: every wave is done with it)
-    float* red = lds;
+        __syncthreads();
+        for (int e = tid; e < (din + 1) * GW_BN; e += 256) {
+            const int j = e / GW_BN, c = e % GW_BN, js = j < din ? j : DP;
+            partial[((tile / ntn) * (din + 1) + j) * N + n0 + c] = red[js * GW_BN + c] + red[((DP + 1) + js) * GW_BN + c];
+        }
+    } else {
+        float* red = lds;
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-        cs[ct] += __shfl_xor(cs[ct], 32);
-        if (h == 0) red[(wave >> 1) * GW_BN + wc + 32 * ct + i] = cs[ct];
+        for (int ct = 0; ct < 2; ++ct) {
+            cs[ct] += __shfl_xor(cs[ct], 32);
+            if (h == 0) red[(wave >> 1) * GW_BN + wc + 32 * ct + i] = cs[ct];
+        }
+        __syncthreads();
+        if (tid < GW_BN) partial[(tile / ntn) * N + n0 + tid] = red[tid] + red[GW_BN + tid];
     }
-    __syncthreads();
-    if (tid < GW_BN) partial[(tile / ntn) * N + n0 + tid] = red[tid] + red[GW_BN + tid];
 }
 
 extern "C" size_t sparc_dgrad_narrow_relu_workspace_bytes(int64_t m, int N) {
@@ -1079,7 +1176,7 @@ extern "C" int sparc_dgrad_narrow_relu(int64_t m, int n_out, int N, const float*
         default: hipLaunchKernelGGL((dgrad_narrow_relu_kernel<4>), grid, dim3(256), 0, stream, m, n_out, N, g, ldg, W, hprev, ldh, dx, ldx, partial, rpb); break;
     }
     SPARC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(colsum_finish, dim3((N + 63) / 64), dim3(64 * COLSUM_LANES), 0, stream, nparts, N, partial, db_prev);
+    hipLaunchKernelGGL(colsum_finish, dim3((N + 63) / 64), dim3(64 * COLSUM_LANES), 0, stream, nparts, N, partial, db_prev, 0);
     SPARC_CHECK_LAUNCH();
     return SPARC_OK;
 }
@@ -1100,10 +1197,44 @@ extern "C" int sparc_dgrad_wide_relu(int64_t m, int K, int N, const float* g, in
     const int64_t mt = (m + GW_BM - 1) / GW_BM, tiles = mt * (N / GW_BN);
     if (tiles > 0x7fffffffLL) return SPARC_ERR_SIZE;
     float* partial = static_cast<float*>(ws);
-    hipLaunchKernelGGL(dgrad_wide_relu_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, m, K, N, g, ldg, W, hprev, ldh, dx,
-                       ldx, partial);
+    hipLaunchKernelGGL(dgrad_wide_relu_kernel<0>, dim3((unsigned)tiles), dim3(256), 0, stream, m, K, N, g, ldg, W, hprev, ldh, dx,
+                       ldx, partial, static_cast<const float*>(nullptr), (int64_t)0, 0, static_cast<const float*>(nullptr),
+                       static_cast<const float*>(nullptr));
     SPARC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(colsum_finish, dim3((N + 63) / 64), dim3(64 * COLSUM_LANES), 0, stream, (int)mt, N, partial, db_prev);
+    hipLaunchKernelGGL(colsum_finish, dim3((N + 63) / 64), dim3(64 * COLSUM_LANES), 0, stream, (int)mt, N, partial, db_prev, 0);
+    SPARC_CHECK_LAUNCH();
+    return SPARC_OK;
+}
+
+extern "C" size_t sparc_dgrad_wide_first_workspace_bytes(int64_t m, int N, int din) {
+    if (m < 0 || N <= 0 || din <= 0) return 0;
+    return sparc_align_up((size_t)((m + GW_BM - 1) / GW_BM) * (size_t)(din + 1) * (size_t)N * sizeof(float)) + 256;
+}
+
+extern "C" int sparc_dgrad_wide_first(int64_t m, int K, int N, int din, const float* g, int64_t ldg, const float* W,
+                                      const float* xin, int64_t ldxi, const float* W0, const float* b0, float* dW_db, void* ws,
+                                      size_t ws_bytes, sparc_stream_t stream) {
+    if (m < 0 || K <= 0 || K % GW_BK != 0 || N <= 0 || N % GW_BN != 0 || din <= 0 || din > 16 || !g || !W || !xin || !W0 || !b0 ||
+        !dW_db || ldg < K || ldg % 4 != 0 || ldxi < din || !aligned16(g) || !aligned16(W))
+        return SPARC_ERR_ARG;
+    if (ws_bytes < sparc_dgrad_wide_first_workspace_bytes(m, N, din) || !ws || (reinterpret_cast<uintptr_t>(ws) & 255)) return SPARC_ERR_WS;
+    if (m == 0)
+        return hipMemsetAsync(dW_db, 0, (size_t)(din + 1) * N * sizeof(float), stream) == hipSuccess ? SPARC_OK : SPARC_ERR_LAUNCH;
+    const int64_t mt = (m + GW_BM - 1) / GW_BM, tiles = mt * (N / GW_BN);
+    if (tiles > 0x7fffffffLL) return SPARC_ERR_SIZE;
+    float* partial = static_cast<float*>(ws);
+#define SPARC_GW_FIRST(DP_)                                                                                                  \
+    hipLaunchKernelGGL(dgrad_wide_relu_kernel<DP_>, dim3((unsigned)tiles), dim3(256), 0, stream, m, K, N, g, ldg, W,             \
+                       static_cast<const float*>(nullptr), (int64_t)0, static_cast<float*>(nullptr), (int64_t)0, partial, xin,   \
+                       ldxi, din, W0, b0)
+    if (din <= 4) SPARC_GW_FIRST(4);
+    else if (din <= 8) SPARC_GW_FIRST(8);
+    else if (din <= 12) SPARC_GW_FIRST(12);
+    else SPARC_GW_FIRST(16);
+#undef SPARC_GW_FIRST
+    SPARC_CHECK_LAUNCH();
+    const int cols = (din + 1) * N;
+    hipLaunchKernelGGL(colsum_finish, dim3((cols + 63) / 64), dim3(64 * COLSUM_LANES), 0, stream, (int)mt, cols, partial, dW_db, din);
     SPARC_CHECK_LAUNCH();
     return SPARC_OK;
 }

@@ -201,6 +201,30 @@ def dgrad_wide_relu(g: torch.Tensor, W: torch.Tensor, hprev: torch.Tensor, db_ou
     return dx, db
 
 
+def dgrad_wide_first(g: torch.Tensor, W: torch.Tensor, x: torch.Tensor, W0: torch.Tensor, b0: torch.Tensor,
+                     out: torch.Tensor = None):
+    """(dW [n, din], db [n]) of the network's first Linear+ReLU layer (input x [m, din], din <= 16, weights W0 [n, din], bias
+    b0, forward on linear_narrow_in_fwd) from the gradient g reaching the NEXT layer's pre-activations and that layer's
+    weights W [K, n]: the product (g W) * [x W0^T + b0 > 0] is summed into the two gradients inside the GEMM's epilogue
+    and never stored, the ReLU derivative recomputed with the forward's arithmetic.  None when the shapes do not fit."""
+    m, K = g.shape
+    N = W.shape[1]
+    din = x.shape[1]
+    if (K % 16 or N % 128 or m == 0 or din > 16 or x.stride(1) != 1 or not g.is_contiguous() or not W.is_contiguous()
+            or not W0.is_contiguous() or not b0.is_contiguous() or tuple(W0.shape) != (N, din)
+            or any(t.dtype != torch.float32 for t in (g, W, x, W0, b0)) or g.data_ptr() % 16 or W.data_ptr() % 16):
+        return None
+    out = _usable(out, ((din + 1) * N,))     # (the weight gradient followed by the bias gradient: a reducer's bucket)
+    if out is None:
+        out = torch.empty((din + 1) * N, dtype=torch.float32, device=g.device)
+    nbytes = lib.sparc_dgrad_wide_first_workspace_bytes(m, N, din)
+    ws = Workspace.get(nbytes, g.device)
+    with torch.cuda.device(g.device):
+        check(lib.sparc_dgrad_wide_first(m, K, N, din, _ptr(g), g.stride(0), _ptr(W), _ptr(x), x.stride(0), _ptr(W0), _ptr(b0),
+                                         _ptr(out), _ptr(ws), nbytes, _stream()), "sparc_dgrad_wide_first")
+    return out[:din * N].view(N, din), out[din * N:]
+
+
 def _destination(hook, l, W, cache):
     """(dW_out, db_out, both) where layer l's gradients should be written so that the hook need not copy them: a hook
     object with a destination(layer, w_shape, b_shape, like) method (a data-parallel reducer's bucket) names them;
@@ -301,6 +325,13 @@ class SpectralMLP(torch.autograd.Function):
             grads[2 * l] = _wgrad(gp, acts[l], Ws[l], _destination(hook, l, Ws[l], dest)[0])
             grads[2 * l + 1] = db
             _layer_done(grads, l, hook)
+            if l == 1 and SpectralMLP.fuse_wide_dgrad and not need_x and ctx.first_own:
+                # layer 0 is the first layer: its gradients are column sums of this product, which is not stored
+                first = dgrad_wide_first(gp, Ws[1], acts[0], Ws[0], b_first, _destination(hook, 0, Ws[0], dest)[2])
+                if first is not None:
+                    grads[0], grads[1] = first
+                    _layer_done(grads, 0, hook)
+                    return (None, None, *grads)
             if l > 1 and SpectralMLP.fuse_wide_dgrad:   # layer l - 1 is a hidden layer behind the first: its ReLU rides along
                 pending = dgrad_wide_relu(gp, Ws[l], acts[l], _destination(hook, l - 1, Ws[l - 1], dest)[1])
                 if pending is None:

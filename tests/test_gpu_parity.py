@@ -529,6 +529,35 @@ def test_dgrad_wide_relu_matches_float64(dev, m, K, N):
     assert dgrad_wide_relu(g[:, :K - 1].contiguous(), W[:K - 1].contiguous(), hprev) is None or (K - 1) % 16 == 0
 
 
+@pytest.mark.parametrize("m,K,N,din", [(3001, 64, 128, 10), (255, 16, 256, 1), (12345, 512, 1024, 16), (770, 48, 128, 5),
+                                         (256, 32, 128, 13)])
+def test_dgrad_wide_first_matches_float64(dev, m, K, N, din):
+    """The first layer's weight and bias gradient out of the epilogue of the product that computes the gradient
+    reaching its output (which is never stored), the ReLU derivative recomputed: against float64 with the mask of the
+    forward kernel's own output, and against the two-step path's layout."""
+    from sparc_amd.ops import ACT_RELU, dgrad_wide_first, linear_narrow_in_fwd
+    gen = torch.Generator().manual_seed(m + K + N + din)
+    g = torch.randn(m, K, generator=gen).to(dev)
+    W = (torch.randn(K, N, generator=gen) / K ** 0.5).to(dev)
+    x = torch.randn(m, din + 2, generator=gen).to(dev)[:, :din]     # (a row stride that is not the width)
+    W0 = torch.randn(N, din, generator=gen).to(dev)
+    b0 = torch.randn(N, generator=gen).to(dev)
+    h0 = linear_narrow_in_fwd(x, W0, b0, ACT_RELU)
+    got = dgrad_wide_first(g, W, x, W0, b0)
+    assert got is not None
+    dW, db = got
+    assert dW.shape == (N, din) and db.shape == (N,)
+    dx = (g.double() @ W.double()) * (h0 > 0)
+    assert rel(dW.cpu().numpy(), (dx.t() @ x.double()).cpu().numpy()) < 1e-5
+    assert rel(db.cpu().numpy(), dx.sum(0).cpu().numpy()) < 1e-5
+    # into a caller's buffer (a reducer's bucket): weight gradient, then bias gradient
+    out = torch.full(((din + 1) * N,), float("nan"), device=dev)
+    dW2, db2 = dgrad_wide_first(g, W, x, W0, b0, out)
+    assert dW2.data_ptr() == out.data_ptr() and db2.data_ptr() == out.data_ptr() + 4 * din * N
+    assert torch.equal(dW2, dW) and torch.equal(db2, db)
+    assert dgrad_wide_first(g, W, torch.randn(m, 17, device=dev), torch.randn(N, 17, device=dev), b0) is None
+
+
 @pytest.mark.parametrize("m,n_out,N", [(3001, 47, 512), (70, 64, 64), (5, 1, 128), (24491, 33, 256)])
 def test_dgrad_narrow_relu_matches_float64(dev, m, n_out, N):
     from sparc_amd.ops import dgrad_narrow_relu

@@ -133,7 +133,7 @@ def test_wide_dgrad_gemm_loop_waits_only_for_the_chunk_it_reads(tmp_path):
     """dgrad_wide_relu_kernel (mlp.hip): its global->LDS copies are issued two chunks ahead, so the product loop must
     wait for the copies of the chunk it is about to read and no further (vmcnt(6) with the next chunk's six copies in
     flight, vmcnt(0) only on the way out), synchronise with a bare s_barrier, and hold 64 matrix instructions per
-    chunk; the kernel fits the registers of two workgroups per CU without spilling, and the outputs of the narrow
+    chunk; every instantiation fits the registers of two workgroups per CU without spilling, and the outputs of the narrow
     forward with the Gram product in its epilogue do not spill either."""
     from sparc_amd import build
     out = tmp_path / "mlp.s"
@@ -142,21 +142,24 @@ def test_wide_dgrad_gemm_loop_waits_only_for_the_chunk_it_reads(tmp_path):
     subprocess.run([hipcc] + flags + ["-S", "--cuda-device-only", "-o", str(out),
                                       os.path.join(ROOT, "sparc_amd", "csrc", "mlp.hip")], check=True, cwd=str(tmp_path))
     text = out.read_text()
-    meta = re.search(r"\.amdhsa_kernel (\S*dgrad_wide_relu_kernel\S*)(.*?)\.end_amdhsa_kernel", text, re.S)
-    assert meta, "dgrad_wide_relu_kernel not found"
-    assert int(re.search(r"\.amdhsa_private_segment_fixed_size\s+(\d+)", meta.group(2)).group(1)) == 0
-    assert int(re.search(r"\.amdhsa_next_free_vgpr\s+(\d+)", meta.group(2)).group(1)) <= 256
-    assert int(re.search(r"\.amdhsa_group_segment_fixed_size\s+(\d+)", meta.group(2)).group(1)) <= 80 * 1024
-    body = re.search(r"^(_Z\w*dgrad_wide_relu_kernel\w*):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M).group(2)
-    ins = [l.split(";")[0].strip() for l in body.splitlines()]
-    ins = [l for l in ins if l and not l.startswith(".")]
-    first_mfma = next(i for i, l in enumerate(ins) if "v_mfma_f32_32x32x2" in l)
-    barrier = max(i for i, l in enumerate(ins[:first_mfma]) if l.startswith("s_barrier"))
-    between = ins[barrier:first_mfma]
-    assert sum("global_load_lds_dwordx4" in l for l in between) == 6
-    assert not any(re.match(r"s_waitcnt.*vmcnt", l) for l in between), between
-    before = [l for l in ins[max(0, barrier - 12):barrier] if l.startswith("s_waitcnt")]
-    assert any("vmcnt(6)" in l for l in before) and not any("lgkmcnt(0)" in l and "vmcnt(0)" in l for l in before), before
-    assert sum("v_mfma_f32_32x32x2" in l for l in ins) == 64
+    metas = list(re.finditer(r"\.amdhsa_kernel (\S*dgrad_wide_relu_kernel\S*)(.*?)\.end_amdhsa_kernel", text, re.S))
+    assert len(metas) == 5, "dgrad_wide_relu_kernel: the plain product and four widths of the first-layer form"
+    for meta in metas:
+        assert int(re.search(r"\.amdhsa_private_segment_fixed_size\s+(\d+)", meta.group(2)).group(1)) == 0, meta.group(1)
+        assert int(re.search(r"\.amdhsa_next_free_vgpr\s+(\d+)", meta.group(2)).group(1)) <= 256, meta.group(1)
+        assert int(re.search(r"\.amdhsa_group_segment_fixed_size\s+(\d+)", meta.group(2)).group(1)) <= 80 * 1024
+    bodies = list(re.finditer(r"^(_Z\w*dgrad_wide_relu_kernel\w*):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M))
+    assert len(bodies) == 5
+    for found in bodies:
+        ins = [l.split(";")[0].strip() for l in found.group(2).splitlines()]
+        ins = [l for l in ins if l and not l.startswith(".")]
+        first_mfma = next(i for i, l in enumerate(ins) if "v_mfma_f32_32x32x2" in l)
+        barrier = max(i for i, l in enumerate(ins[:first_mfma]) if l.startswith("s_barrier"))
+        between = ins[barrier:first_mfma]
+        assert sum("global_load_lds_dwordx4" in l for l in between) == 6
+        assert not any(re.match(r"s_waitcnt.*vmcnt", l) for l in between), between
+        before = [l for l in ins[max(0, barrier - 12):barrier] if l.startswith("s_waitcnt")]
+        assert any("vmcnt(6)" in l for l in before) and not any("lgkmcnt(0)" in l and "vmcnt(0)" in l for l in before), before
+        assert sum("v_mfma_f32_32x32x2" in l for l in ins) == 64
     for m in re.finditer(r"\.amdhsa_kernel (\S*linear_narrow_fwd_kernel\S*)(.*?)\.end_amdhsa_kernel", text, re.S):
         assert int(re.search(r"\.amdhsa_private_segment_fixed_size\s+(\d+)", m.group(2)).group(1)) == 0, m.group(1)
