@@ -343,7 +343,9 @@ def main():
         dist.barrier()
     # HIP events around the inner row-gather passes (epilogue 1), on the launch stream
     if not args.hip_graph:   # (events recorded inside a captured graph carry no time: measured after the run instead)
-        check(lib.sparc_profile_begin(1, args.steps), "sparc_profile_begin")   # one event pair per step: both inner passes
+        # one event pair per step around both inner passes, on the first 32 steps of the timed region (a pair costs the
+        # stream about as much as one of the passes it brackets: event_pair_with_nothing_between_us)
+        check(lib.sparc_profile_begin(1, min(args.steps, 32)), "sparc_profile_begin")
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     nodes = 0
@@ -397,7 +399,7 @@ def main():
 
     if rank == 0:
         kern_ms = tot_ms.value / max(launches.value, 1)
-        per_launch = alg_bytes / max(2 * args.steps, 1)
+        per_launch = alg_bytes / max(2 * args.steps, 1)   # (the average over all steps' batches; the batches cycle)
         achieved = per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         b0 = trainer.batches[0]
         path = b0.pass_kernel(k, True)

@@ -268,6 +268,15 @@ int sparc_orth_weights(int64_t m, int k, const double* G, const float* Yt, int64
                        const int32_t* top_idx, int mode, float* Wo,
                        double* Rc, double* Rinv, double* signs, int32_t* info,
                        sparc_stream_t stream);
+/* sparc_orth_weights for a caller that holds the top rows' numbers on the HOST, as the reference does (the first k
+ * entries of numpy's permutation, src/SpectralTrainer.py:216-224): top_idx_host[0 .. n_idx) is read during the call and
+ * travels inside the kernel's arguments, so no copy to the device (and no wait for one) sits in the middle of the
+ * forward pass.  n_idx <= 64; entries beyond n_idx, and row numbers outside [0, m), count as rows of zeros.  Not for
+ * code under stream capture: the numbers would be frozen into the graph. */
+int sparc_orth_weights_host_idx(int64_t m, int k, const double* G, const float* Yt, int64_t ld,
+                                const int32_t* top_idx_host, int n_idx, int mode, float* Wo,
+                                double* Rc, double* Rinv, double* signs, int32_t* info,
+                                sparc_stream_t stream);
 int sparc_orth_apply(int64_t m, int k, const float* Yt, int64_t ld, const float* Wo,
                      int transpose_w, float* Z, int64_t ldz, sparc_stream_t stream);
 int sparc_orth_weights_bwd(int64_t m, int k, const double* gWo, const double* Rc,

@@ -68,6 +68,7 @@ _SIGS = {
     "sparc_gram_reduce": (c_int, [c_int, c_int, P, P, P]),
     "sparc_gram_apply": (c_int, [c_int64, c_int, P, c_int64, P, c_int64, P, P, c_int, P, c_int64, P, c_size_t, P]),
     "sparc_orth_weights": (c_int, [c_int64, c_int, P, P, c_int64, P, c_int, P, P, P, P, P, P]),
+    "sparc_orth_weights_host_idx": (c_int, [c_int64, c_int, P, P, c_int64, P, c_int, c_int, P, P, P, P, P, P]),
     "sparc_orth_apply": (c_int, [c_int64, c_int, P, c_int64, P, c_int, P, c_int64, P]),
     "sparc_orth_weights_bwd": (c_int, [c_int64, c_int, P, P, P, P, c_int, P, P]),
     "sparc_orth_weights_bwd_f64": (c_int, [c_int64, c_int, P, P, P, P, c_int, P, P]),

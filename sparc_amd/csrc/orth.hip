@@ -408,12 +408,19 @@ __device__ __forceinline__ void trailing_update(const int jb, const int nt, cons
 // Yt[top] X and its sign-tracking LU).  (Four waves with the trailing matrix in registers, one barrier per column
 // as well: 83 us against 63 us at k = 47; a column costs 1200-1450 cycles either way: the barrier, two LDS round
 // trips and the reciprocal square root chain, not the arithmetic.)
+// (head: the top rows' numbers handed over inside the kernel arguments, when the caller had them on the host)
+struct HeadRows {
+    int32_t idx[SPARC_MAX_K];
+    int given;
+};
+
 __global__ __launch_bounds__(OW_THREADS) void orth_weights_kernel(int64_t m, int k, const double* __restrict__ G,
                                                                   const float* __restrict__ Yt, int64_t ld,
                                                                   const int32_t* __restrict__ top_idx, int mode,
                                                                   float* __restrict__ Wo, double* __restrict__ Rc_out,
                                                                   double* __restrict__ Rinv_out,
-                                                                  double* __restrict__ signs_out, int32_t* __restrict__ info) {
+                                                                  double* __restrict__ signs_out, int32_t* __restrict__ info,
+                                                                  const HeadRows head) {
     __shared__ double R[SPARC_MAX_K * KLD];
     __shared__ double X[SPARC_MAX_K * KLD];
     __shared__ double Q[SPARC_MAX_K * KLD];
@@ -440,7 +447,7 @@ __global__ __launch_bounds__(OW_THREADS) void orth_weights_kernel(int64_t m, int
         gv[u] = e < k * k ? G[e] : 0.0;
         tv[u] = 0.f;
         if (mode == 0 && e < k * k) {
-            const int64_t row = top_idx ? top_idx[e / k] : e / k;
+            const int64_t row = top_idx ? top_idx[e / k] : head.given ? head.idx[e / k] : e / k;
             if (row < m) tv[u] = Yt[row * ld + e % k];   // top rows of Yt
         }
     }
@@ -876,8 +883,27 @@ extern "C" int sparc_orth_weights(int64_t m, int k, const double* G, const float
     if (m <= 0 || k < 1 || k > SPARC_MAX_K || !G || !Yt || ld < k || !Wo || !Rc || !Rinv || !signs || !info ||
         (mode != 0 && mode != 1))
         return SPARC_ERR_ARG;
+    HeadRows head = {};
     hipLaunchKernelGGL(orth_weights_kernel, dim3(1), dim3(OW_THREADS), 0, stream, m, k, G, Yt, ld, top_idx, mode, Wo, Rc, Rinv,
-                       signs, info);
+                       signs, info, head);
+    SPARC_CHECK_LAUNCH();
+    return SPARC_OK;
+}
+
+extern "C" int sparc_orth_weights_host_idx(int64_t m, int k, const double* G, const float* Yt, int64_t ld,
+                                           const int32_t* top_idx_host, int n_idx, int mode, float* Wo, double* Rc,
+                                           double* Rinv, double* signs, int32_t* info, sparc_stream_t stream) {
+    if (m <= 0 || k < 1 || k > SPARC_MAX_K || !G || !Yt || ld < k || !Wo || !Rc || !Rinv || !signs || !info ||
+        (mode != 0 && mode != 1) || !top_idx_host || n_idx < 0 || n_idx > SPARC_MAX_K)
+        return SPARC_ERR_ARG;
+    HeadRows head;
+    head.given = 1;
+    for (int j = 0; j < SPARC_MAX_K; ++j) {
+        const int64_t r = j < n_idx ? top_idx_host[j] : m;   // beyond the list, and anything out of range: a row of zeros
+        head.idx[j] = (r < 0 || r > m) ? static_cast<int32_t>(m < 0x7fffffff ? m : 0x7fffffff) : static_cast<int32_t>(r);
+    }
+    hipLaunchKernelGGL(orth_weights_kernel, dim3(1), dim3(OW_THREADS), 0, stream, m, k, G, Yt, ld,
+                       static_cast<const int32_t*>(nullptr), mode, Wo, Rc, Rinv, signs, info, head);
     SPARC_CHECK_LAUNCH();
     return SPARC_OK;
 }

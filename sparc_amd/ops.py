@@ -469,47 +469,12 @@ class SplitRows(torch.autograd.Function):
         return torch.cat([g1, g2], dim=0), None
 
 
-class _IndexStaging:
-    """Pinned host buffers through which short index lists reach the device without stopping the host: a copy from
-    pageable memory returns only when the stream has got to it, i.e. after every kernel enqueued before it, and a
-    training step hands over the k leading rows of its permutation in the middle of the forward pass."""
-    RING, WIDTH = 16, 64
-
-    def __init__(self):
-        self.host = [torch.empty(self.WIDTH, dtype=torch.int32).pin_memory() for _ in range(self.RING)]
-        self.done = [None] * self.RING     # event after the copy out of each buffer
-        self.turn = 0
-
-    def send(self, values: np.ndarray, dev) -> torch.Tensor:
-        slot = self.turn % self.RING
-        self.turn += 1
-        if self.done[slot] is not None:
-            self.done[slot].synchronize()   # RING copies back: long finished unless the host runs that far ahead
-        n = values.shape[0]
-        self.host[slot].numpy()[:n] = values
-        out = torch.empty(n, dtype=torch.int32, device=dev)
-        out.copy_(self.host[slot][:n], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(dev))
-        self.done[slot] = ev
-        return out
-
-
-_index_staging = {}
-
-
 def _index_to_device(idx, dev) -> torch.Tensor:
-    """int32 device copy of a short index list; host lists of up to 64 entries travel asynchronously."""
+    """int32 device copy of an index list (a device tensor stays where it is)."""
     if torch.is_tensor(idx) and idx.device == dev:
         return idx.to(torch.int32).contiguous()
     arr = np.ascontiguousarray(idx.cpu().numpy() if torch.is_tensor(idx) else np.asarray(idx)).astype(np.int32, copy=False)
-    if arr.ndim != 1 or arr.shape[0] > _IndexStaging.WIDTH or torch.cuda.is_current_stream_capturing():
-        return torch.as_tensor(arr, device=dev)
-    key = dev.index or 0
-    if key not in _index_staging:
-        _index_staging[key] = _IndexStaging()
-    with torch.cuda.device(dev):
-        return _index_staging[key].send(arr, dev)
+    return torch.as_tensor(arr, device=dev)
 
 
 class OrthWeights(torch.autograd.Function):
@@ -575,6 +540,17 @@ class OrthWeights(torch.autograd.Function):
         Rc, Rinv, signs = saved[:k * k], saved[k * k:2 * k * k], saved[2 * k * k:]
         info = OrthWeights._info_slot(dev)   # written by every call
         tidx = None
+        if top_idx is not None and not (torch.is_tensor(top_idx) and top_idx.is_cuda) and not torch.cuda.is_current_stream_capturing():
+            # row numbers on the host (the reference's numpy permutation): they travel in the kernel's arguments
+            arr = np.ascontiguousarray(top_idx.numpy() if torch.is_tensor(top_idx) else np.asarray(top_idx))
+            if arr.ndim == 1:
+                arr = np.clip(arr[:k], -1, m).astype(np.int32)   # (only the first k are used; out of range = a row of zeros)
+                with torch.cuda.device(dev):
+                    check(lib.sparc_orth_weights_host_idx(m, k, _ptr(G), _ptr(Y), Y.stride(0), arr.ctypes.data, int(arr.shape[0]),
+                                                          int(mode), _ptr(Wo), _ptr(Rc), _ptr(Rinv), _ptr(signs), _ptr(info),
+                                                          _stream()), "sparc_orth_weights_host_idx")
+                OrthWeights.last_info = info
+                return Wo, saved
         if top_idx is not None:
             tidx = _index_to_device(top_idx, dev)
             if tidx.numel() < k:  # batches with fewer than k rows: pad with out-of-range rows (read as zero)

@@ -93,7 +93,7 @@ def test_out_of_range_widths_are_rejected_before_any_launch():
     """Entry points whose kernels are built for k (or a narrow width) up to 64 refuse 65 with an argument / size error
     instead of launching: non-null pointers, plausible row counts, every int argument 65."""
     from sparc_amd import _lib
-    narrow = ["sparc_gram", "sparc_gram_static", "sparc_orth_weights", "sparc_orth_apply", "sparc_orth_weights_bwd",
+    narrow = ["sparc_gram", "sparc_gram_static", "sparc_orth_weights", "sparc_orth_weights_host_idx", "sparc_orth_apply", "sparc_orth_weights_bwd",
               "sparc_orth_weights_bwd_f64", "sparc_orth_apply_f64", "sparc_act_bwd_bias", "sparc_wgrad_small",
               "sparc_first_layer_bwd", "sparc_linear_narrow_fwd", "sparc_linear_narrow_fwd_gram", "sparc_dgrad_narrow_relu",
               "sparc_gram_reduce", "sparc_gram_apply", "sparc_dgrad_wide_relu", "sparc_dgrad_wide_first"]

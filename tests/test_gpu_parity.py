@@ -334,6 +334,15 @@ def test_orth_signs_follow_top_rows(dev):
     ref = O.orthonorm_weights_qr(Yt[torch.as_tensor(perm)].double()).numpy()
     Wo = OrthWeights.apply(Yt.to(dev), perm[:16], 0).cpu().numpy()
     assert rel(Wo, ref) < 1e-5
+    # row numbers on the host travel in the kernel's arguments, row numbers on the device are read there: same bits;
+    # a list shorter than k and row numbers out of range stand for rows of zeros either way
+    on_dev = torch.as_tensor(perm[:16].astype(np.int32), device=dev)
+    assert np.array_equal(OrthWeights.apply(Yt.to(dev), on_dev, 0).cpu().numpy(), Wo)
+    short = np.concatenate([perm[:11], [300, 300, 300, 300, 300]])
+    a = OrthWeights.apply(Yt.to(dev), perm[:11], 0).cpu().numpy()
+    b = OrthWeights.apply(Yt.to(dev), torch.as_tensor(short.astype(np.int32), device=dev), 0).cpu().numpy()
+    c = OrthWeights.apply(Yt.to(dev), np.concatenate([perm[:11], [-1, 300, 99999, 301, 300]]), 0).cpu().numpy()
+    assert np.array_equal(a, b) and np.array_equal(a, c)
     Wc = OrthWeights.apply(Yt.to(dev), None, 1).cpu().numpy()
     assert rel(Wc, O.orthonorm_weights_chol(Yt.double(), torch.ones(16, dtype=torch.float64)).numpy()) < 1e-6
 
@@ -597,9 +606,9 @@ def test_spectral_mlp_matches_torch_layers(dev, dims, x_grad):
 
 
 def test_permutation_heads_from_the_host_travel_asynchronously_and_intact(dev):
-    """Host index lists reach the orthonormalisation through a ring of pinned staging buffers (no host stop inside
-    the forward pass): forty calls in a row without a synchronisation in between, more than twice round the ring,
-    give what the same heads give as device tensors; lists longer than a staging buffer take the blocking copy."""
+    """Host index lists reach the orthonormalisation inside its kernel arguments (no copy and no host stop inside the
+    forward pass): forty calls in a row without a synchronisation in between give what the same heads give as device
+    tensors; a list longer than k counts with its first k entries."""
     from sparc_amd import ops
     torch.manual_seed(2)
     rng = np.random.default_rng(2)
@@ -611,12 +620,11 @@ def test_permutation_heads_from_the_host_travel_asynchronously_and_intact(dev):
     for h, w in zip(heads, got):
         ref = ops.OrthWeights.apply(Y, torch.as_tensor(h, device=dev, dtype=torch.int32), 0)
         assert torch.equal(w, ref)
-    assert ops._index_staging[dev.index or 0].turn >= 40
-    long_list = rng.permutation(m)[:ops._IndexStaging.WIDTH + 5]
-    t = ops._index_to_device(long_list, dev)
-    assert t.dtype == torch.int32 and np.array_equal(t.cpu().numpy(), long_list)
+    long_list = np.concatenate([heads[0], rng.permutation(m)[:70]])
+    assert torch.equal(ops.OrthWeights.apply(Y, long_list, 0), got[0])
+    assert torch.equal(ops.OrthWeights.apply(Y, torch.as_tensor(heads[0]), 0), got[0])   # a host tensor
     assert ops._index_to_device(torch.arange(5, device=dev), dev).dtype == torch.int32
-    assert np.array_equal(ops._index_to_device(torch.arange(7), dev).cpu().numpy(), np.arange(7))   # a host tensor
+    assert np.array_equal(ops._index_to_device(torch.arange(7), dev).cpu().numpy(), np.arange(7))
 
 
 @pytest.mark.parametrize("m,K,N,act", [(1537, 10, 1024, 0), (1, 3, 4, 2), (5000, 16, 2052, 1), (333, 1, 64, 0),
