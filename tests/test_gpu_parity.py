@@ -539,7 +539,7 @@ def test_dgrad_wide_relu_matches_float64(dev, m, K, N):
 
 
 @pytest.mark.parametrize("m,K,N,din", [(3001, 64, 128, 10), (255, 16, 256, 1), (12345, 512, 1024, 16), (770, 48, 128, 5),
-                                         (256, 32, 128, 13)])
+                                         (256, 32, 128, 13), (48979, 1024, 1024, 10)])
 def test_dgrad_wide_first_matches_float64(dev, m, K, N, din):
     """The first layer's weight and bias gradient out of the epilogue of the product that computes the gradient
     reaching its output (which is never stored), the ReLU derivative recomputed: against float64 with the mask of the
